@@ -1,0 +1,177 @@
+/*
+ * rpe_amd.h -- C-ABI of the MI355X-native relative-pose engine.
+ *
+ * Drop-in boundary for ONE path of ofekm5/relative-pose-estimation:
+ *   PoseEstimator.estimate(img1, img2)  (reference src/core/pose_estimator.py:487-569)
+ *     = ORB detectAndCompute x2        (:85-91, :108, :505-506)
+ *     -> BFMatcher(HAMMING, crossCheck=True).match + sorted + [:max_matches]  (:131, :144-151)
+ *     -> gather matched points                                         (:518-519)
+ *     -> cv2.findEssentialMat(RANSAC, 0.999, 1.0)                       (:522-527)
+ *     -> cv2.recoverPose                                               (:533)
+ *
+ * The reference has no FFI (it is Python calling cv2); the entry points below
+ * are what a ctypes binding for that path binds (INTEGRATION.md shows the
+ * stub).  Plain pointers and sizes only; no torch / numpy types.
+ *
+ * Conventions
+ *  - every function returns an int status: 0 = OK, <0 = library error
+ *    (rpe_last_error() gives text).  Per-pair outcomes are reported in the
+ *    status[] output array (RPE_PAIR_*), never as a failed call: a batch
+ *    does not abort on one bad pair (the reference raises RuntimeError,
+ *    pose_estimator.py:508-509,514-515,529-530; the Python wrapper maps the
+ *    per-pair code back to the same exception text).
+ *  - a handle owns one HIP device, one stream and its workspaces; it is not
+ *    thread-safe; different handles are independent (one per GPU).
+ *  - pointers named h_* are host memory, d_* are device (HBM) memory.
+ *  - images are uint8 gray, row-major, tightly packed H x W, one after another.
+ *  - matrices are row-major doubles: K[9], R[9] per pair, t[3] per pair.
+ *  - results are bit-deterministic run to run (integer atomics only).
+ */
+#ifndef RPE_AMD_H
+#define RPE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPE_ABI_VERSION 1
+#define RPE_ORB_LEVELS 12
+
+/* per-pair status codes (status[] outputs) */
+enum {
+    RPE_PAIR_OK = 0,
+    RPE_PAIR_NO_DESCRIPTORS = 1,       /* pose_estimator.py:508-509 */
+    RPE_PAIR_INSUFFICIENT_MATCHES = 2, /* pose_estimator.py:514-515 */
+    RPE_PAIR_NO_ESSENTIAL = 3          /* pose_estimator.py:529-530 */
+};
+
+/* library error codes (function return values) */
+enum {
+    RPE_OK = 0,
+    RPE_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+    RPE_ERR_HIP = -2,       /* HIP runtime failure (no device, OOM, launch error) */
+    RPE_ERR_CAPACITY = -3   /* batch larger than the handle's max_batch */
+};
+
+enum { RPE_FEATURE_ORB = 0, RPE_FEATURE_SIFT = 1 };
+enum { RPE_NORM_HAMMING = 0, RPE_NORM_L2 = 1 };
+
+/* Mirrors PoseEstimator.__init__ kwargs (pose_estimator.py:19-32) plus the
+ * constants hard-coded at the reference's cv2 call sites. */
+typedef struct rpe_config {
+    int32_t abi_version;      /* RPE_ABI_VERSION */
+    int32_t device;           /* HIP device ordinal */
+    int32_t width, height;    /* image size served by this handle */
+    int32_t max_batch;        /* max pairs per call */
+    int32_t feature_method;   /* RPE_FEATURE_ORB        (pose_estimator.py:22) */
+    int32_t norm_type;        /* RPE_NORM_HAMMING       (pose_estimator.py:23) */
+    int32_t max_matches;      /* default 500            (pose_estimator.py:24) */
+    int32_t nfeatures;        /* default 4000           (pose_estimator.py:25) */
+    int32_t fast_threshold;   /* 15                     (pose_estimator.py:89) */
+    int32_t ransac_max_iters; /* 1000 (cv2 default maxIters) */
+    double  ransac_prob;      /* 0.999                  (pose_estimator.py:525) */
+    double  ransac_threshold; /* 1.0 px                 (pose_estimator.py:526) */
+} rpe_config;
+
+typedef struct rpe_handle rpe_handle;
+
+/* ORB keypoint record returned by the stage API (cv2.KeyPoint fields the path uses) */
+typedef struct rpe_keypoint {
+    float x, y;          /* kp.pt  (level coordinates * level scale) */
+    float angle;         /* kp.angle, degrees */
+    float response;      /* kp.response (Harris) */
+    int32_t octave;      /* kp.octave */
+    int32_t lx, ly;      /* integer coordinates inside the pyramid level */
+} rpe_keypoint;
+
+/* ------------------------------------------------------------ lifecycle */
+void rpe_default_config(rpe_config *cfg);
+/* replaces PoseEstimator.__init__ / _create_feature_extractor / _create_matcher
+ * (pose_estimator.py:19-69, :75-96, :115-131) */
+int rpe_create(const rpe_config *cfg, rpe_handle **out);
+void rpe_destroy(rpe_handle *h);
+const char *rpe_last_error(const rpe_handle *h); /* h may be NULL: last create error */
+int rpe_device_count(void);
+/* capacity of per-image keypoint arrays used by the stage API */
+int rpe_keypoint_capacity(const rpe_handle *h);
+
+/* ------------------------------------------------------- device buffers */
+/* thin wrappers so a ctypes host can keep image batches resident in HBM */
+int rpe_device_malloc(rpe_handle *h, size_t bytes, void **d_ptr);
+int rpe_device_free(rpe_handle *h, void *d_ptr);
+int rpe_memcpy_h2d(rpe_handle *h, void *d_dst, const void *h_src, size_t bytes);
+int rpe_memcpy_d2h(rpe_handle *h, void *h_dst, const void *d_src, size_t bytes);
+int rpe_synchronize(rpe_handle *h);
+
+/* ------------------------------------------------------------- hot path */
+/* replaces PoseEstimator.estimate (pose_estimator.py:487-533) for B pairs.
+ * h_imgs1/h_imgs2: B images each (host).  Outputs (host, caller-allocated):
+ * R[B*9], t[B*3], inliers[B] (= recoverPose return value, :621),
+ * n_matches[B] (= len(matches), :627; may be NULL), status[B]. */
+int rpe_estimate_batch(rpe_handle *h, const uint8_t *h_imgs1, const uint8_t *h_imgs2, int B,
+                       const double K[9], double *R, double *t, int32_t *inliers,
+                       int32_t *n_matches, int32_t *status);
+/* same, images already resident in HBM (the timed configuration) */
+int rpe_estimate_batch_device(rpe_handle *h, const uint8_t *d_imgs1, const uint8_t *d_imgs2, int B,
+                              const double K[9], double *R, double *t, int32_t *inliers,
+                              int32_t *n_matches, int32_t *status);
+/* asynchronous form: enqueue on the handle's stream, results stay on the
+ * device until rpe_fetch_results(); lets the host overlap the next upload. */
+int rpe_enqueue_batch_device(rpe_handle *h, const uint8_t *d_imgs1, const uint8_t *d_imgs2, int B,
+                             const double K[9]);
+int rpe_fetch_results(rpe_handle *h, int B, double *R, double *t, int32_t *inliers,
+                      int32_t *n_matches, int32_t *status);
+/* matched point arrays of the last batch (estimate_with_debug's pts1/pts2,
+ * pose_estimator.py:606-607,628-629): pts[B*max_matches*2] f32 */
+int rpe_fetch_matched_points(rpe_handle *h, int B, float *pts1, float *pts2);
+
+/* ---------------------------------------------------------- stage entry */
+/* replaces extractor.detectAndCompute(image, None) (pose_estimator.py:108)
+ * for n_images images (n_images <= 2*max_batch).  kps[n_images*cap],
+ * desc[n_images*cap*32], counts[n_images]; cap = rpe_keypoint_capacity(). */
+int rpe_orb_detect_and_compute(rpe_handle *h, const uint8_t *h_imgs, int n_images,
+                               rpe_keypoint *kps, uint8_t *desc, int32_t *counts);
+/* intermediate images of image `index` of the last ORB run, in the ORACLE's
+ * packed pyramid layout (levels back to back, total = sum w_l*h_l):
+ * which = 0 pyramid, 1 FAST score map, 2 NMS map, 3 blurred pyramid */
+int rpe_orb_debug_fetch(rpe_handle *h, int index, int which, uint8_t *h_out);
+int64_t rpe_orb_pyramid_pixels(const rpe_handle *h);
+
+/* replaces matcher.match + sorted + truncate (pose_estimator.py:144-151) for B
+ * descriptor-set pairs.  desc1/desc2: B*cap*32 bytes (cap = keypoint
+ * capacity), n1/n2: B counts.  Outputs sized B*max_matches. */
+int rpe_match_hamming(rpe_handle *h, const uint8_t *h_desc1, const int32_t *n1,
+                      const uint8_t *h_desc2, const int32_t *n2, int B,
+                      int32_t *qidx, int32_t *tidx, int32_t *dist, int32_t *n_matches);
+
+/* replaces cv2.findEssentialMat(pts1, pts2, K, RANSAC, prob, threshold)
+ * (pose_estimator.py:522-527).  pts: B*max_matches*2 f32, m[B] counts.
+ * Outputs: E[B*9], mask[B*max_matches], found[B], info[B*4] =
+ * {best_count, best_iter, best_model, iters_run}. */
+int rpe_find_essential(rpe_handle *h, const float *h_pts1, const float *h_pts2, const int32_t *m, int B,
+                       const double K[9], double *E, uint8_t *mask, int32_t *found, int32_t *info);
+
+/* replaces cv2.recoverPose(E, pts1, pts2, K) (pose_estimator.py:533) */
+int rpe_recover_pose(rpe_handle *h, const double *h_E, const float *h_pts1, const float *h_pts2,
+                     const int32_t *m, int B, const double K[9],
+                     double *R, double *t, int32_t *inliers);
+
+/* ------------------------------------------------------------ profiling */
+/* Per-stage device time of the last hot-path call, from hipEvents recorded
+ * on the handle's stream around each kernel group. */
+enum {
+    RPE_STAGE_PYRAMID = 0, RPE_STAGE_FAST, RPE_STAGE_NMS, RPE_STAGE_SELECT, RPE_STAGE_HARRIS,
+    RPE_STAGE_KEYPOINTS, RPE_STAGE_ANGLE, RPE_STAGE_BLUR, RPE_STAGE_DESCRIBE, RPE_STAGE_MATCH,
+    RPE_STAGE_RANSAC, RPE_STAGE_POSE, RPE_STAGE_COUNT
+};
+int rpe_set_profiling(rpe_handle *h, int enable);
+int rpe_get_stage_ms(rpe_handle *h, float *ms /* RPE_STAGE_COUNT */);
+const char *rpe_stage_name(int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPE_AMD_H */

@@ -1,0 +1,552 @@
+/*
+ * geom_oracle.c -- TEST INFRASTRUCTURE (see oracle.h).  CPU restatement of
+ *   cv2.findEssentialMat(pts1, pts2, K, RANSAC, 0.999, 1.0)  (reference
+ *   src/core/pose_estimator.py:522-527) and cv2.recoverPose(E, pts1, pts2, K)
+ *   (pose_estimator.py:533).
+ *
+ * Follows OpenCV 4.x calib3d/five-point.cpp (EMEstimatorCallback, findEssentialMat,
+ * decomposeEssentialMat, recoverPose), calib3d/ptsetreg.cpp
+ * (RANSACPointSetRegistrator::run, getSubset, RANSACUpdateNumIters),
+ * calib3d/triangulate.cpp and core/rand.cpp.  Control flow, RNG stream, error
+ * metric (Sampson, f64 -> f32 compare), update rule and tie orders follow those
+ * sources; the minimal solver is Nister's five-point algorithm restated with
+ * its own linear algebra (Householder null space, Gauss-Jordan, real-root
+ * isolation by nested derivatives) because OpenCV's generated coefficient code
+ * and solvePoly cannot be reproduced offline -- mathematically the same root
+ * set; model ORDER inside one sample (ascending z) is this file's own
+ * convention.  "parity unpinned" vs cv2 at E level.
+ *
+ * All arithmetic is plain IEEE f64 with -ffp-contract=off so that the HIP
+ * kernels (which use the same operation order) can be compared bit-for-bit.
+ */
+#include "oracle.h"
+#include <math.h>
+#include <float.h>
+#include <string.h>
+#include <stdlib.h>
+
+/* ------------------------------------------------------------------ RNG */
+/* cv::RNG::next(): state = (uint32)state * 4164903690 + (state >> 32) */
+uint32_t orc_rng_next(uint64_t *state)
+{
+    *state = (uint64_t)(uint32_t)(*state) * 4164903690ULL + (uint32_t)(*state >> 32);
+    return (uint32_t)(*state);
+}
+
+/* ptsetreg.cpp getSubset(): 5 distinct indices, duplicates redrawn at once;
+ * RNG seeded with (uint64)-1 once per run().  The stream depends only on M. */
+void orc_ransac_subsets(int M, int iters, int32_t *idx)
+{
+    uint64_t st = 0xFFFFFFFFFFFFFFFFULL;
+    for (int it = 0; it < iters; ++it) {
+        int32_t *s = idx + it * 5;
+        for (int i = 0; i < 5; ++i) {
+            int v, dup;
+            do {
+                v = (int)(orc_rng_next(&st) % (uint32_t)M);
+                dup = 0;
+                for (int k = 0; k < i; ++k) if (s[k] == v) dup = 1;
+            } while (dup);
+            s[i] = v;
+        }
+    }
+}
+
+static int cv_round(double v) { return (int)lrint(v); } /* round-half-even */
+
+int orc_ransac_update_niters(double p, double ep, int model_points, int max_iters)
+{
+    p = p > 0. ? p : 0.;  p = p < 1. ? p : 1.;
+    ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
+    double num = (1. - p) > DBL_MIN ? (1. - p) : DBL_MIN;
+    double denom = 1. - pow(1. - ep, model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return (denom >= 0 || -num >= max_iters * (-denom)) ? max_iters : cv_round(num / denom);
+}
+
+/* ------------------------------------------------ polynomial bookkeeping */
+/* monomial exponent tables. lin: x y z 1 ; quad: x2 y2 z2 xy xz yz x y z 1 ;
+ * cubic in Nister's elimination order:
+ * x3 y3 x2y xy2 x2z x2 y2z y2 xyz xy | xz2 xz x yz2 yz y z3 z2 z 1 */
+static const int8_t LIN_E[4][3]  = {{1,0,0},{0,1,0},{0,0,1},{0,0,0}};
+static const int8_t QUAD_E[10][3] = {{2,0,0},{0,2,0},{0,0,2},{1,1,0},{1,0,1},{0,1,1},{1,0,0},{0,1,0},{0,0,1},{0,0,0}};
+static const int8_t CUB_E[20][3] = {{3,0,0},{0,3,0},{2,1,0},{1,2,0},{2,0,1},{2,0,0},{0,2,1},{0,2,0},{1,1,1},{1,1,0},
+                                    {1,0,2},{1,0,1},{1,0,0},{0,1,2},{0,1,1},{0,1,0},{0,0,3},{0,0,2},{0,0,1},{0,0,0}};
+static int8_t LL2Q[4][4];   /* lin*lin -> quad index */
+static int8_t QL2C[10][4];  /* quad*lin -> cubic index */
+static int tables_ready = 0;
+
+static void init_tables(void)
+{
+    if (tables_ready) return;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        int e0 = LIN_E[i][0] + LIN_E[j][0], e1 = LIN_E[i][1] + LIN_E[j][1], e2 = LIN_E[i][2] + LIN_E[j][2];
+        for (int q = 0; q < 10; ++q)
+            if (QUAD_E[q][0] == e0 && QUAD_E[q][1] == e1 && QUAD_E[q][2] == e2) LL2Q[i][j] = (int8_t)q;
+    }
+    for (int i = 0; i < 10; ++i) for (int j = 0; j < 4; ++j) {
+        int e0 = QUAD_E[i][0] + LIN_E[j][0], e1 = QUAD_E[i][1] + LIN_E[j][1], e2 = QUAD_E[i][2] + LIN_E[j][2];
+        for (int c = 0; c < 20; ++c)
+            if (CUB_E[c][0] == e0 && CUB_E[c][1] == e1 && CUB_E[c][2] == e2) QL2C[i][j] = (int8_t)c;
+    }
+    tables_ready = 1;
+}
+
+/* c(quad) += a(lin)*b(lin) */
+static void ll_acc(double *c, const double *a, const double *b)
+{
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) c[LL2Q[i][j]] += a[i] * b[j];
+}
+/* c(cubic) += s * a(quad)*b(lin) */
+static void ql_acc(double *c, const double *a, const double *b, double s)
+{
+    for (int i = 0; i < 10; ++i) for (int j = 0; j < 4; ++j) c[QL2C[i][j]] += s * (a[i] * b[j]);
+}
+
+/* ------------------------------------------------- real roots of a poly */
+static double horner(const double *c, int n, double x)
+{
+    double acc = c[n];
+    for (int i = n - 1; i >= 0; --i) acc = acc * x + c[i];
+    return acc;
+}
+
+/* Real roots (ascending) of c[0]+c[1]x+...+c[n]x^n, c[n] != 0, n <= 10.
+ * Nested-derivative isolation: the real roots of p^(k+1) split the line into
+ * intervals on which p^(k) is monotone; each sign change is bisected to f64
+ * resolution.  Sign convention: s(v) = (v > 0). */
+static int poly_real_roots(const double *c, int n, double *roots)
+{
+    double d[11][11];      /* d[k] = coefficients of the polynomial of degree k in the chain */
+    double rts[2][11];
+    int nr_prev = 0, cur = 0;
+    /* d[n] = p; d[k-1] = derivative of d[k] */
+    for (int i = 0; i <= n; ++i) d[n][i] = c[i];
+    for (int k = n; k >= 2; --k)
+        for (int i = 0; i < k; ++i) d[k - 1][i] = d[k][i + 1] * (double)(i + 1);
+    /* degree 1 */
+    rts[0][0] = -d[1][0] / d[1][1];
+    nr_prev = 1; cur = 0;
+    for (int k = 2; k <= n; ++k) {
+        const double *p = d[k];
+        const double *crit = rts[cur];
+        double *out = rts[cur ^ 1];
+        int nout = 0;
+        double mx = 0.;
+        for (int i = 0; i < k; ++i) { double a = fabs(p[i]); if (a > mx) mx = a; }
+        double R = 1. + mx / fabs(p[k]);
+        if (!(R < 1e12)) R = 1e12;
+        for (int iv = 0; iv <= nr_prev; ++iv) {
+            double a = (iv == 0) ? -R : crit[iv - 1];
+            double b = (iv == nr_prev) ? R : crit[iv];
+            if (a < -R) a = -R;
+            if (b > R) b = R;
+            if (!(a < b)) continue;
+            int sa = horner(p, k, a) > 0., sb = horner(p, k, b) > 0.;
+            if (sa == sb) continue;
+            double lo = a, hi = b;
+            for (int it = 0; it < 200; ++it) {
+                double mid = 0.5 * (lo + hi);
+                if (!(mid > lo && mid < hi)) break;
+                int sm = horner(p, k, mid) > 0.;
+                if (sm == sa) lo = mid; else hi = mid;
+            }
+            out[nout++] = 0.5 * (lo + hi);
+        }
+        nr_prev = nout; cur ^= 1;
+        if (nout == 0 && k < n) {
+            /* derivative chain without real critical points: p^(k) monotone-free;
+             * continue with an empty split (single interval) */
+        }
+    }
+    for (int i = 0; i < nr_prev; ++i) roots[i] = rts[cur][i];
+    return nr_prev;
+}
+
+/* --------------------------------------------------- five-point solver */
+/* Restates EMEstimatorCallback::runKernel (five-point.cpp): null space of the
+ * 5x9 epipolar system, 10 cubic constraints (det E = 0, 2EE'E - tr(EE')E = 0),
+ * Gauss-Jordan on Nister's monomial order, 3x3 polynomial matrix B(z),
+ * det B = degree-10 polynomial, real roots, back-substitution, unit-norm E. */
+int orc_five_point(const double *x1, const double *x2, double *E_out)
+{
+    init_tables();
+    /* A = Q^T (9x5): column k = epipolar row of correspondence k, row-major E ordering */
+    double A[9][5];
+    for (int k = 0; k < 5; ++k) {
+        double a = x1[2 * k], b = x1[2 * k + 1], c = x2[2 * k], d = x2[2 * k + 1];
+        A[0][k] = c * a; A[1][k] = c * b; A[2][k] = c;
+        A[3][k] = d * a; A[4][k] = d * b; A[5][k] = d;
+        A[6][k] = a;     A[7][k] = b;     A[8][k] = 1.;
+    }
+    /* Householder QR of A; v_k stored in hv[k][k..8], beta_k */
+    double hv[5][9], beta[5];
+    for (int k = 0; k < 5; ++k) {
+        double nrm = 0.;
+        for (int i = k; i < 9; ++i) nrm += A[i][k] * A[i][k];
+        nrm = sqrt(nrm);
+        double alpha = A[k][k] > 0. ? -nrm : nrm;
+        for (int i = 0; i < 9; ++i) hv[k][i] = 0.;
+        hv[k][k] = A[k][k] - alpha;
+        for (int i = k + 1; i < 9; ++i) hv[k][i] = A[i][k];
+        double vn = 0.;
+        for (int i = k; i < 9; ++i) vn += hv[k][i] * hv[k][i];
+        beta[k] = vn > 0. ? 2. / vn : 0.;
+        for (int j = k; j < 5; ++j) {
+            double s = 0.;
+            for (int i = k; i < 9; ++i) s += hv[k][i] * A[i][j];
+            s *= beta[k];
+            for (int i = k; i < 9; ++i) A[i][j] -= s * hv[k][i];
+        }
+    }
+    /* null basis n_m = H0 H1 H2 H3 H4 e_{5+m}; Eb[m] as lin-poly coefficient of x,y,z,1 */
+    double Eb[4][9];
+    for (int m = 0; m < 4; ++m) {
+        double v[9];
+        for (int i = 0; i < 9; ++i) v[i] = 0.;
+        v[5 + m] = 1.;
+        for (int k = 4; k >= 0; --k) {
+            double s = 0.;
+            for (int i = k; i < 9; ++i) s += hv[k][i] * v[i];
+            s *= beta[k];
+            for (int i = k; i < 9; ++i) v[i] -= s * hv[k][i];
+        }
+        for (int i = 0; i < 9; ++i) Eb[m][i] = v[i];
+    }
+    /* E entry (r,c) as linear polynomial: coefficients [x,y,z,1] */
+    double El[9][4];
+    for (int e = 0; e < 9; ++e) for (int m = 0; m < 4; ++m) El[e][m] = Eb[m][e];
+
+    /* EEt (symmetric, quad) */
+    double EEt[3][3][10];
+    memset(EEt, 0, sizeof(EEt));
+    for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) {
+        for (int k = 0; k < 3; ++k) ll_acc(EEt[i][j], El[i * 3 + k], El[j * 3 + k]);
+        if (j != i) memcpy(EEt[j][i], EEt[i][j], sizeof(double) * 10);
+    }
+    double htr[10];
+    for (int q = 0; q < 10; ++q) htr[q] = 0.5 * ((EEt[0][0][q] + EEt[1][1][q]) + EEt[2][2][q]);
+    for (int i = 0; i < 3; ++i) for (int q = 0; q < 10; ++q) EEt[i][i][q] -= htr[q];
+
+    double Mx[10][20];
+    memset(Mx, 0, sizeof(Mx));
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+        for (int k = 0; k < 3; ++k) ql_acc(Mx[i * 3 + j], EEt[i][k], El[k * 3 + j], 1.);
+    /* det(E) */
+    {
+        double m0[10], m1[10], m2[10];
+        memset(m0, 0, sizeof(m0)); memset(m1, 0, sizeof(m1)); memset(m2, 0, sizeof(m2));
+        double neg[4];
+        /* m0 = E11E22 - E12E21 */
+        ll_acc(m0, El[4], El[8]); for (int q = 0; q < 4; ++q) neg[q] = -El[5][q]; ll_acc(m0, neg, El[7]);
+        /* m1 = E10E22 - E12E20 */
+        ll_acc(m1, El[3], El[8]); ll_acc(m1, neg, El[6]);
+        /* m2 = E10E21 - E11E20 */
+        ll_acc(m2, El[3], El[7]); for (int q = 0; q < 4; ++q) neg[q] = -El[4][q]; ll_acc(m2, neg, El[6]);
+        ql_acc(Mx[9], m0, El[0], 1.);
+        ql_acc(Mx[9], m1, El[1], -1.);
+        ql_acc(Mx[9], m2, El[2], 1.);
+    }
+    /* Gauss-Jordan with partial pivoting on the first 10 columns */
+    for (int c = 0; c < 10; ++c) {
+        int piv = c; double best = fabs(Mx[c][c]);
+        for (int r = c + 1; r < 10; ++r) { double a = fabs(Mx[r][c]); if (a > best) { best = a; piv = r; } }
+        if (best == 0.) return 0;
+        if (piv != c) for (int j = 0; j < 20; ++j) { double t = Mx[c][j]; Mx[c][j] = Mx[piv][j]; Mx[piv][j] = t; }
+        double inv = 1. / Mx[c][c];
+        for (int j = c; j < 20; ++j) Mx[c][j] *= inv;
+        for (int r = 0; r < 10; ++r) {
+            if (r == c) continue;
+            double f = Mx[r][c];
+            if (f == 0.) continue;
+            for (int j = c; j < 20; ++j) Mx[r][j] -= f * Mx[c][j];
+        }
+    }
+    /* B(z): rows <e>-z<f>, <g>-z<h>, <i>-z<j>; columns: x (deg3), y (deg3), 1 (deg4);
+     * polynomial coefficient arrays are stored low degree first */
+    double Bx[3][4], By[3][4], B1[3][5];
+    for (int i = 0; i < 3; ++i) {
+        const double *e = &Mx[4 + 2 * i][10], *f = &Mx[5 + 2 * i][10];
+        /* e: [xz2 xz x yz2 yz y z3 z2 z 1] */
+        Bx[i][3] = -f[0]; Bx[i][2] = e[0] - f[1]; Bx[i][1] = e[1] - f[2]; Bx[i][0] = e[2];
+        By[i][3] = -f[3]; By[i][2] = e[3] - f[4]; By[i][1] = e[4] - f[5]; By[i][0] = e[5];
+        B1[i][4] = -f[6]; B1[i][3] = e[6] - f[7]; B1[i][2] = e[7] - f[8]; B1[i][1] = e[8] - f[9]; B1[i][0] = e[9];
+    }
+    /* det B = sum_i B1[i] * cof_i, cof_i = (-1)^i-style 2x2 minors of (Bx,By) */
+    double c10[11];
+    for (int i = 0; i < 11; ++i) c10[i] = 0.;
+    for (int i = 0; i < 3; ++i) {
+        int r0 = (i + 1) % 3, r1 = (i + 2) % 3;
+        double minor[7];
+        for (int k = 0; k < 7; ++k) minor[k] = 0.;
+        for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b)
+            minor[a + b] += Bx[r0][a] * By[r1][b] - Bx[r1][a] * By[r0][b];
+        for (int a = 0; a < 7; ++a) for (int b = 0; b < 5; ++b) c10[a + b] += minor[a] * B1[i][b];
+    }
+    int n = 10;
+    for (; n > 1; --n) if (fabs(c10[n]) > DBL_EPSILON) break;
+    double roots[10];
+    int nroots = poly_real_roots(c10, n, roots);
+    int count = 0;
+    for (int ri = 0; ri < nroots && count < 10; ++ri) {
+        double z = roots[ri];
+        double bz[3][3];
+        for (int i = 0; i < 3; ++i) {
+            bz[i][0] = ((Bx[i][3] * z + Bx[i][2]) * z + Bx[i][1]) * z + Bx[i][0];
+            bz[i][1] = ((By[i][3] * z + By[i][2]) * z + By[i][1]) * z + By[i][0];
+            bz[i][2] = (((B1[i][4] * z + B1[i][3]) * z + B1[i][2]) * z + B1[i][1]) * z + B1[i][0];
+        }
+        /* null vector of bz: best-conditioned row cross product */
+        double bestn = -1., xv[3] = {0, 0, 0};
+        for (int i = 0; i < 3; ++i) {
+            int r0 = i, r1 = (i + 1) % 3;
+            double cx = bz[r0][1] * bz[r1][2] - bz[r0][2] * bz[r1][1];
+            double cy = bz[r0][2] * bz[r1][0] - bz[r0][0] * bz[r1][2];
+            double cz = bz[r0][0] * bz[r1][1] - bz[r0][1] * bz[r1][0];
+            double nn = cx * cx + cy * cy + cz * cz;
+            if (nn > bestn) { bestn = nn; xv[0] = cx; xv[1] = cy; xv[2] = cz; }
+        }
+        if (!(bestn > 0.)) continue;
+        double inv = 1. / sqrt(bestn);
+        double w = xv[2] * inv;
+        if (fabs(w) < 1e-10) continue;
+        double x = xv[0] / xv[2], y = xv[1] / xv[2];
+        double Ev[9], nrm = 0.;
+        for (int e = 0; e < 9; ++e) {
+            Ev[e] = ((Eb[0][e] * x + Eb[1][e] * y) + Eb[2][e] * z) + Eb[3][e];
+            nrm += Ev[e] * Ev[e];
+        }
+        nrm = sqrt(nrm);
+        if (!(nrm > 0.)) continue;
+        for (int e = 0; e < 9; ++e) E_out[count * 9 + e] = Ev[e] / nrm;
+        ++count;
+    }
+    return count;
+}
+
+/* ----------------------------------------------------------- RANSAC */
+/* EMEstimatorCallback::computeError (Sampson, f64 then cast f32) +
+ * findInliers: err <= (float)(thr*thr) */
+static int count_inliers(const double *E, const double *n1, const double *n2, int M, float thr2, uint8_t *mask)
+{
+    int cnt = 0;
+    for (int i = 0; i < M; ++i) {
+        double x1 = n1[2 * i], y1 = n1[2 * i + 1], x2 = n2[2 * i], y2 = n2[2 * i + 1];
+        double Ex0 = (E[0] * x1 + E[1] * y1) + E[2];
+        double Ex1 = (E[3] * x1 + E[4] * y1) + E[5];
+        double Ex2 = (E[6] * x1 + E[7] * y1) + E[8];
+        double Et0 = (E[0] * x2 + E[3] * y2) + E[6];
+        double Et1 = (E[1] * x2 + E[4] * y2) + E[7];
+        double x2tEx1 = (x2 * Ex0 + y2 * Ex1) + Ex2;
+        double a = Ex0 * Ex0, b = Ex1 * Ex1, c = Et0 * Et0, d = Et1 * Et1;
+        float err = (float)(x2tEx1 * x2tEx1 / (((a + b) + c) + d));
+        int f = err <= thr2;
+        if (mask) mask[i] = (uint8_t)f;
+        cnt += f;
+    }
+    return cnt;
+}
+
+int orc_find_essential(const float *pts1, const float *pts2, int M, const double *K,
+                       double prob, double threshold, int max_iters,
+                       double *E, uint8_t *mask, orc_ransac_info *info)
+{
+    orc_ransac_info li; memset(&li, 0, sizeof(li));
+    li.best_iter = -1; li.best_model = -1;
+    if (info) *info = li;
+    if (M < 5) return 0;
+    double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    double *n1 = (double *)malloc(sizeof(double) * 4 * (size_t)M), *n2 = n1 + 2 * (size_t)M;
+    for (int i = 0; i < M; ++i) {
+        n1[2 * i] = ((double)pts1[2 * i] - cx) / fx; n1[2 * i + 1] = ((double)pts1[2 * i + 1] - cy) / fy;
+        n2[2 * i] = ((double)pts2[2 * i] - cx) / fx; n2[2 * i + 1] = ((double)pts2[2 * i + 1] - cy) / fy;
+    }
+    double thr = threshold / ((fx + fy) / 2);
+    float thr2 = (float)(thr * thr);
+    double models[90];
+    int ok = 0;
+    if (M == 5) {
+        /* ptsetreg.cpp: count == modelPoints -> runKernel on all points; OpenCV
+         * returns every model stacked; this restatement keeps the first. */
+        int nm = orc_five_point(n1, n2, models);
+        if (nm > 0) {
+            memcpy(E, models, sizeof(double) * 9);
+            if (mask) memset(mask, 1, (size_t)M);
+            li.found = 1; li.best_count = 5; li.best_iter = 0; li.best_model = 0; li.iters_run = 1;
+            ok = 1;
+        }
+    } else {
+        int niters = max_iters, best = 0;
+        uint64_t st = 0xFFFFFFFFFFFFFFFFULL;
+        uint8_t *cur = (uint8_t *)malloc((size_t)M);
+        int iter;
+        for (iter = 0; iter < niters; ++iter) {
+            int s[5];
+            double s1[10], s2[10];
+            for (int i = 0; i < 5; ++i) {
+                int v, dup;
+                do {
+                    v = (int)(orc_rng_next(&st) % (uint32_t)M);
+                    dup = 0;
+                    for (int k = 0; k < i; ++k) if (s[k] == v) dup = 1;
+                } while (dup);
+                s[i] = v;
+                s1[2 * i] = n1[2 * v]; s1[2 * i + 1] = n1[2 * v + 1];
+                s2[2 * i] = n2[2 * v]; s2[2 * i + 1] = n2[2 * v + 1];
+            }
+            int nm = orc_five_point(s1, s2, models);
+            for (int m = 0; m < nm; ++m) {
+                int good = count_inliers(models + 9 * m, n1, n2, M, thr2, cur);
+                int lim = best > 4 ? best : 4;
+                if (good > lim) {
+                    best = good;
+                    memcpy(E, models + 9 * m, sizeof(double) * 9);
+                    if (mask) memcpy(mask, cur, (size_t)M);
+                    li.best_iter = iter; li.best_model = m;
+                    niters = orc_ransac_update_niters(prob, (double)(M - good) / M, 5, niters);
+                }
+            }
+        }
+        free(cur);
+        li.iters_run = iter;
+        li.best_count = best;
+        li.found = best > 0;
+        ok = best > 0;
+    }
+    free(n1);
+    if (info) *info = li;
+    return ok;
+}
+
+/* ----------------------------------------------- one-sided Jacobi SVD */
+/* A (m x n, row-major, leading dim n) is overwritten by A*V; V (n x n) gets the
+ * right singular vectors.  Hestenes rotations, eps = 10*DBL_EPSILON, <= 30
+ * sweeps (core/lapack.cpp JacobiSVDImpl_ uses the same criterion). */
+static void jacobi_cols(double *A, double *V, int m, int n)
+{
+    const double eps = DBL_EPSILON * 10;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1. : 0.;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        int changed = 0;
+        for (int p = 0; p < n - 1; ++p) for (int q = p + 1; q < n; ++q) {
+            double al = 0., be = 0., ga = 0.;
+            for (int k = 0; k < m; ++k) {
+                double ap = A[k * n + p], aq = A[k * n + q];
+                al += ap * ap; be += aq * aq; ga += ap * aq;
+            }
+            if (fabs(ga) <= eps * sqrt(al * be)) continue;
+            changed = 1;
+            double zeta = (be - al) / (2. * ga);
+            double t = (zeta >= 0. ? 1. : -1.) / (fabs(zeta) + sqrt(1. + zeta * zeta));
+            double c = 1. / sqrt(1. + t * t), s = c * t;
+            for (int k = 0; k < m; ++k) {
+                double ap = A[k * n + p], aq = A[k * n + q];
+                A[k * n + p] = c * ap - s * aq; A[k * n + q] = s * ap + c * aq;
+            }
+            for (int k = 0; k < n; ++k) {
+                double vp = V[k * n + p], vq = V[k * n + q];
+                V[k * n + p] = c * vp - s * vq; V[k * n + q] = s * vp + c * vq;
+            }
+        }
+        if (!changed) break;
+    }
+}
+
+static double det3(const double *m)
+{
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+/* decomposeEssentialMat (five-point.cpp): SVD, det fix, R1 = U W Vt, R2 = U Wt Vt, t = U[:,2] */
+void orc_decompose_essential(const double *E, double *R1, double *R2, double *t)
+{
+    double A[9], V[9];
+    memcpy(A, E, sizeof(A));
+    jacobi_cols(A, V, 3, 3);
+    double sv[3];
+    int ord[3] = {0, 1, 2};
+    for (int j = 0; j < 3; ++j) sv[j] = sqrt((A[j] * A[j] + A[3 + j] * A[3 + j]) + A[6 + j] * A[6 + j]);
+    /* sort descending (stable) */
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2 - i; ++j)
+        if (sv[ord[j]] < sv[ord[j + 1]]) { int tt = ord[j]; ord[j] = ord[j + 1]; ord[j + 1] = tt; }
+    double U[9], Vt[9];
+    for (int c = 0; c < 2; ++c) {
+        int j = ord[c];
+        double s = sv[j] > 0. ? 1. / sv[j] : 0.;
+        for (int r = 0; r < 3; ++r) U[r * 3 + c] = A[r * 3 + j] * s;
+    }
+    /* third left vector: u0 x u1 (sigma3 = 0 for an essential matrix) */
+    U[2] = U[3] * U[7] - U[6] * U[4];
+    U[5] = U[6] * U[1] - U[0] * U[7];
+    U[8] = U[0] * U[4] - U[3] * U[1];
+    for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) Vt[c * 3 + r] = V[r * 3 + ord[c]];
+    if (det3(U) < 0) for (int i = 0; i < 9; ++i) U[i] = -U[i];
+    if (det3(Vt) < 0) for (int i = 0; i < 9; ++i) Vt[i] = -Vt[i];
+    /* U*W: columns (-u1, u0, u2); U*Wt: (u1, -u0, u2) with W = [[0,1,0],[-1,0,0],[0,0,1]] */
+    double UW[9], UWt[9];
+    for (int r = 0; r < 3; ++r) {
+        UW[r * 3 + 0] = -U[r * 3 + 1]; UW[r * 3 + 1] = U[r * 3 + 0]; UW[r * 3 + 2] = U[r * 3 + 2];
+        UWt[r * 3 + 0] = U[r * 3 + 1]; UWt[r * 3 + 1] = -U[r * 3 + 0]; UWt[r * 3 + 2] = U[r * 3 + 2];
+    }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+        R1[r * 3 + c] = (UW[r * 3] * Vt[c] + UW[r * 3 + 1] * Vt[3 + c]) + UW[r * 3 + 2] * Vt[6 + c];
+        R2[r * 3 + c] = (UWt[r * 3] * Vt[c] + UWt[r * 3 + 1] * Vt[3 + c]) + UWt[r * 3 + 2] * Vt[6 + c];
+    }
+    t[0] = U[2]; t[1] = U[5]; t[2] = U[8];
+}
+
+/* triangulate one point (triangulate.cpp) with P0 = [I|0], P = [R|t] and test
+ * the cheirality conditions of recoverPose (distanceThresh = 50). */
+static int cheirality_one(const double *R, const double *t, double x1, double y1, double x2, double y2)
+{
+    double A[16], V[16];
+    A[0] = -1.; A[1] = 0.;  A[2] = x1; A[3] = 0.;
+    A[4] = 0.;  A[5] = -1.; A[6] = y1; A[7] = 0.;
+    for (int k = 0; k < 3; ++k) {
+        A[8 + k]  = x2 * R[6 + k] - R[k];
+        A[12 + k] = y2 * R[6 + k] - R[3 + k];
+    }
+    A[11] = x2 * t[2] - t[0];
+    A[15] = y2 * t[2] - t[1];
+    jacobi_cols(A, V, 4, 4);
+    int jm = 0; double best = 0.;
+    for (int j = 0; j < 4; ++j) {
+        double nn = ((A[j] * A[j] + A[4 + j] * A[4 + j]) + A[8 + j] * A[8 + j]) + A[12 + j] * A[12 + j];
+        if (j == 0 || nn < best) { best = nn; jm = j; }
+    }
+    double X = V[jm], Y = V[4 + jm], Z = V[8 + jm], W = V[12 + jm];
+    int good = (Z * W) > 0.;
+    X /= W; Y /= W; Z /= W;
+    good = good && (Z < 50.);
+    double z2 = ((R[6] * X + R[7] * Y) + R[8] * Z) + t[2];
+    good = good && (z2 > 0.) && (z2 < 50.);
+    return good;
+}
+
+int orc_recover_pose(const double *E, const float *pts1, const float *pts2, int M,
+                     const double *K, double *R, double *t)
+{
+    double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    double R1[9], R2[9], tt[3], tn[3];
+    orc_decompose_essential(E, R1, R2, tt);
+    tn[0] = -tt[0]; tn[1] = -tt[1]; tn[2] = -tt[2];
+    int g1 = 0, g2 = 0, g3 = 0, g4 = 0;
+    for (int i = 0; i < M; ++i) {
+        double x1 = ((double)pts1[2 * i] - cx) / fx, y1 = ((double)pts1[2 * i + 1] - cy) / fy;
+        double x2 = ((double)pts2[2 * i] - cx) / fx, y2 = ((double)pts2[2 * i + 1] - cy) / fy;
+        g1 += cheirality_one(R1, tt, x1, y1, x2, y2);
+        g2 += cheirality_one(R2, tt, x1, y1, x2, y2);
+        g3 += cheirality_one(R1, tn, x1, y1, x2, y2);
+        g4 += cheirality_one(R2, tn, x1, y1, x2, y2);
+    }
+    const double *Rs; const double *ts; int g;
+    if (g1 >= g2 && g1 >= g3 && g1 >= g4)      { Rs = R1; ts = tt; g = g1; }
+    else if (g2 >= g1 && g2 >= g3 && g2 >= g4) { Rs = R2; ts = tt; g = g2; }
+    else if (g3 >= g1 && g3 >= g2 && g3 >= g4) { Rs = R1; ts = tn; g = g3; }
+    else                                        { Rs = R2; ts = tn; g = g4; }
+    memcpy(R, Rs, sizeof(double) * 9);
+    memcpy(t, ts, sizeof(double) * 3);
+    return g;
+}

@@ -1,0 +1,93 @@
+/*
+ * match_oracle.c -- TEST INFRASTRUCTURE (see oracle.h).  CPU restatement of
+ *   cv2.BFMatcher(norm, crossCheck=True).match(desc1, desc2)
+ *   (reference src/core/pose_estimator.py:131,144) followed by the reference's
+ *   own Python post-processing: stable sort by distance (:147) and
+ *   truncation to max_matches (:150-151).
+ *
+ * crossCheck semantics follow OpenCV core/batch_distance.cpp
+ * (batchDistance(..., crosscheck=true)): every train row elects its nearest
+ * query (strict '<' scanning queries ascending => lowest query index on
+ * ties); every query keeps, among the trains that elected it, the one with
+ * the smallest distance (strict '<' scanning trains ascending => lowest train
+ * index on ties); matches are emitted in ascending query index.  Python's
+ * sorted() is stable, so the final order is (distance, queryIdx).
+ */
+#include "oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <limits.h>
+
+static int hamming32(const uint8_t *a, const uint8_t *b)
+{
+    int d = 0;
+    for (int k = 0; k < 32; ++k) d += __builtin_popcount((unsigned)(a[k] ^ b[k]));
+    return d;
+}
+
+int orc_match_hamming(const uint8_t *d1, int n1, const uint8_t *d2, int n2,
+                      int max_matches, int32_t *qidx, int32_t *tidx, int32_t *dist)
+{
+    if (n1 <= 0 || n2 <= 0) return 0;
+    int *best_d = (int *)malloc(sizeof(int) * (size_t)n1);
+    int *best_t = (int *)malloc(sizeof(int) * (size_t)n1);
+    for (int i = 0; i < n1; ++i) { best_d[i] = INT_MAX; best_t[i] = -1; }
+    for (int j = 0; j < n2; ++j) {
+        int bi = -1, bd = INT_MAX;
+        for (int i = 0; i < n1; ++i) {
+            int d = hamming32(d1 + 32 * (size_t)i, d2 + 32 * (size_t)j);
+            if (d < bd) { bd = d; bi = i; }
+        }
+        if (bd < best_d[bi]) { best_d[bi] = bd; best_t[bi] = j; }
+    }
+    /* stable sort by distance == counting sort over 0..256 in ascending query index */
+    int n = 0;
+    int lim = max_matches >= 0 ? max_matches : INT_MAX;
+    for (int d = 0; d <= 256 && n < lim; ++d)
+        for (int i = 0; i < n1 && n < lim; ++i)
+            if (best_t[i] >= 0 && best_d[i] == d) { qidx[n] = i; tidx[n] = best_t[i]; dist[n] = d; ++n; }
+    free(best_d); free(best_t);
+    return n;
+}
+
+typedef struct { float d; int q, t; } l2m;
+
+static int cmp_l2(const void *a, const void *b)
+{
+    const l2m *x = (const l2m *)a, *y = (const l2m *)b;
+    if (x->d < y->d) return -1;
+    if (x->d > y->d) return 1;
+    return x->q - y->q; /* stability: ascending query index */
+}
+
+/* NORM_L2 on SIFT-style descriptors (integer-valued f32 in 0..255): the squared
+ * distance is exact in int64; the reported distance is the f32 sqrt, and the
+ * sort key is that f32 value (distinct integers may collide after sqrt). */
+int orc_match_l2(const float *d1, int n1, const float *d2, int n2, int dim,
+                 int max_matches, int32_t *qidx, int32_t *tidx, float *dist)
+{
+    if (n1 <= 0 || n2 <= 0) return 0;
+    float *best_d = (float *)malloc(sizeof(float) * (size_t)n1);
+    int *best_t = (int *)malloc(sizeof(int) * (size_t)n1);
+    for (int i = 0; i < n1; ++i) { best_d[i] = INFINITY; best_t[i] = -1; }
+    for (int j = 0; j < n2; ++j) {
+        int bi = -1; float bd = INFINITY;
+        for (int i = 0; i < n1; ++i) {
+            const float *a = d1 + (size_t)dim * i, *b = d2 + (size_t)dim * j;
+            float s = 0.f;
+            for (int k = 0; k < dim; ++k) { float df = a[k] - b[k]; s += df * df; }
+            float d = sqrtf(s);
+            if (d < bd) { bd = d; bi = i; }
+        }
+        if (bi >= 0 && bd < best_d[bi]) { best_d[bi] = bd; best_t[bi] = j; }
+    }
+    l2m *m = (l2m *)malloc(sizeof(l2m) * (size_t)n1);
+    int n = 0;
+    for (int i = 0; i < n1; ++i) if (best_t[i] >= 0) { m[n].d = best_d[i]; m[n].q = i; m[n].t = best_t[i]; ++n; }
+    qsort(m, (size_t)n, sizeof(l2m), cmp_l2);
+    if (max_matches >= 0 && n > max_matches) n = max_matches;
+    for (int i = 0; i < n; ++i) { qidx[i] = m[i].q; tidx[i] = m[i].t; dist[i] = m[i].d; }
+    free(m); free(best_d); free(best_t);
+    return n;
+}

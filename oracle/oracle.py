@@ -1,0 +1,215 @@
+"""ctypes loader for the CPU oracle (TEST INFRASTRUCTURE -- see oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  The shipped package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "build", "liboracle.so")
+ORB_LEVELS = 12
+
+
+def build(force=False):
+    """Compile oracle/*.c with gcc (Makefile in this directory)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class Keypoint(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("angle", C.c_float), ("response", C.c_float),
+                ("octave", C.c_int32), ("lx", C.c_int32), ("ly", C.c_int32)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("lx", "<i4"), ("ly", "<i4")])
+
+
+class Layout(C.Structure):
+    _fields_ = [("w", C.c_int32 * ORB_LEVELS), ("h", C.c_int32 * ORB_LEVELS),
+                ("quota", C.c_int32 * ORB_LEVELS), ("scale", C.c_float * ORB_LEVELS),
+                ("offset", C.c_int64 * ORB_LEVELS), ("total", C.c_int64)]
+
+
+class RansacInfo(C.Structure):
+    _fields_ = [("found", C.c_int32), ("best_count", C.c_int32), ("best_iter", C.c_int32),
+                ("best_model", C.c_int32), ("iters_run", C.c_int32)]
+
+
+class PoseResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_kp1", C.c_int32), ("n_kp2", C.c_int32),
+                ("n_matches", C.c_int32), ("inliers", C.c_int32),
+                ("R", C.c_double * 9), ("t", C.c_double * 3)]
+
+
+POSE_DTYPE = np.dtype([("status", "<i4"), ("n_kp1", "<i4"), ("n_kp2", "<i4"), ("n_matches", "<i4"),
+                       ("inliers", "<i4"), ("_pad", "<i4"), ("R", "<f8", (9,)), ("t", "<f8", (3,))])
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_rng_next.restype = C.c_uint32
+        _lib.orc_fast_atan2.restype = C.c_float
+        _lib.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _lib.orc_orb_pattern.restype = C.POINTER(C.c_int8)
+        _lib.orc_ransac_update_niters.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+        _lib.orc_find_essential.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double,
+                                            C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        assert C.sizeof(PoseResult) == POSE_DTYPE.itemsize
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def rng_stream(n, seed=0xFFFFFFFFFFFFFFFF):
+    st = C.c_uint64(seed)
+    return [lib().orc_rng_next(C.byref(st)) for _ in range(n)]
+
+
+def ransac_subsets(M, iters=1000):
+    idx = np.zeros((iters, 5), np.int32)
+    lib().orc_ransac_subsets(M, iters, _p(idx))
+    return idx
+
+
+def update_niters(p, ep, model_points, max_iters):
+    return lib().orc_ransac_update_niters(p, ep, model_points, max_iters)
+
+
+def match_hamming(d1, d2, max_matches=500):
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    n1, n2 = len(d1), len(d2)
+    cap = max(n1, 1)
+    q = np.zeros(cap, np.int32); t = np.zeros(cap, np.int32); d = np.zeros(cap, np.int32)
+    n = lib().orc_match_hamming(_p(d1), n1, _p(d2), n2, int(max_matches), _p(q), _p(t), _p(d))
+    return q[:n].copy(), t[:n].copy(), d[:n].copy()
+
+
+def match_l2(d1, d2, max_matches=500):
+    d1 = np.ascontiguousarray(d1, np.float32); d2 = np.ascontiguousarray(d2, np.float32)
+    n1, n2 = len(d1), len(d2)
+    cap = max(n1, 1)
+    q = np.zeros(cap, np.int32); t = np.zeros(cap, np.int32); d = np.zeros(cap, np.float32)
+    n = lib().orc_match_l2(_p(d1), n1, _p(d2), n2, d1.shape[1], int(max_matches), _p(q), _p(t), _p(d))
+    return q[:n].copy(), t[:n].copy(), d[:n].copy()
+
+
+def five_point(x1, x2):
+    x1 = np.ascontiguousarray(x1, np.float64); x2 = np.ascontiguousarray(x2, np.float64)
+    E = np.zeros((10, 9), np.float64)
+    n = lib().orc_five_point(_p(x1), _p(x2), _p(E))
+    return E[:n].reshape(n, 3, 3).copy()
+
+
+def find_essential(pts1, pts2, K, prob=0.999, threshold=1.0, max_iters=1000):
+    pts1 = np.ascontiguousarray(pts1, np.float32); pts2 = np.ascontiguousarray(pts2, np.float32)
+    K = np.ascontiguousarray(K, np.float64)
+    M = len(pts1)
+    E = np.zeros(9, np.float64); mask = np.zeros(max(M, 1), np.uint8); info = RansacInfo()
+    ok = lib().orc_find_essential(_p(pts1), _p(pts2), M, _p(K), prob, threshold, max_iters, _p(E), _p(mask),
+                                  C.addressof(info))
+    inf = {f: getattr(info, f) for f, _ in RansacInfo._fields_}
+    return (E.reshape(3, 3) if ok else None), mask[:M].copy(), inf
+
+
+def recover_pose(E, pts1, pts2, K):
+    pts1 = np.ascontiguousarray(pts1, np.float32); pts2 = np.ascontiguousarray(pts2, np.float32)
+    E = np.ascontiguousarray(E, np.float64); K = np.ascontiguousarray(K, np.float64)
+    R = np.zeros(9); t = np.zeros(3)
+    n = lib().orc_recover_pose(_p(E), _p(pts1), _p(pts2), len(pts1), _p(K), _p(R), _p(t))
+    return n, R.reshape(3, 3), t.reshape(3, 1)
+
+
+def decompose_essential(E):
+    E = np.ascontiguousarray(E, np.float64)
+    R1 = np.zeros(9); R2 = np.zeros(9); t = np.zeros(3)
+    lib().orc_decompose_essential(_p(E), _p(R1), _p(R2), _p(t))
+    return R1.reshape(3, 3), R2.reshape(3, 3), t
+
+
+def orb_layout(W, H, nfeatures):
+    L = Layout()
+    lib().orc_orb_layout_init(W, H, nfeatures, C.byref(L))
+    return L
+
+
+def orb_detect_and_compute(img, nfeatures=4000, fast_threshold=15, cap=None):
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    cap = cap or nfeatures + 64
+    kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+    n = lib().orc_orb_detect_and_compute(_p(img), W, H, nfeatures, fast_threshold, _p(kps), _p(desc), cap)
+    return kps[:n].copy(), desc[:n].copy()
+
+
+def build_pyramid(img, nfeatures=1000):
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    L = orb_layout(W, H, nfeatures)
+    pyr = np.zeros(L.total, np.uint8)
+    lib().orc_orb_build_pyramid(_p(img), W, H, C.byref(L), _p(pyr))
+    return pyr, L
+
+
+def fast_score_map(lvl, thr=15):
+    lvl = np.ascontiguousarray(lvl, np.uint8)
+    h, w = lvl.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().orc_orb_fast_score_map(_p(lvl), w, h, thr, _p(out))
+    return out
+
+
+def nms_map(score):
+    score = np.ascontiguousarray(score, np.uint8)
+    h, w = score.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().orc_orb_nms_map(_p(score), w, h, _p(out))
+    return out
+
+
+def blur_level(lvl):
+    lvl = np.ascontiguousarray(lvl, np.uint8)
+    h, w = lvl.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().orc_orb_blur_level(_p(lvl), w, h, _p(out))
+    return out
+
+
+def fast_atan2(y, x):
+    return lib().orc_fast_atan2(float(y), float(x))
+
+
+def orb_pattern():
+    p = lib().orc_orb_pattern()
+    return np.array([p[i] for i in range(1024)], np.int8).reshape(256, 4)
+
+
+def estimate_pose(img1, img2, K, nfeatures=4000, max_matches=500):
+    img1 = np.ascontiguousarray(img1, np.uint8); img2 = np.ascontiguousarray(img2, np.uint8)
+    K = np.ascontiguousarray(K, np.float64)
+    H, W = img1.shape
+    res = PoseResult()
+    lib().orc_estimate_pose(_p(img1), _p(img2), W, H, _p(K), nfeatures, max_matches, C.byref(res))
+    return {"status": res.status, "n_kp1": res.n_kp1, "n_kp2": res.n_kp2, "n_matches": res.n_matches,
+            "inliers": res.inliers, "R": np.array(res.R).reshape(3, 3), "t": np.array(res.t).reshape(3, 1)}
+
+
+def estimate_pose_batch(imgs1, imgs2, K, nfeatures=4000, max_matches=500, nthreads=1):
+    imgs1 = np.ascontiguousarray(imgs1, np.uint8); imgs2 = np.ascontiguousarray(imgs2, np.uint8)
+    K = np.ascontiguousarray(K, np.float64)
+    B, H, W = imgs1.shape
+    out = np.zeros(B, POSE_DTYPE)
+    lib().orc_estimate_pose_batch(_p(imgs1), _p(imgs2), B, W, H, _p(K), nfeatures, max_matches, _p(out), nthreads)
+    return out
