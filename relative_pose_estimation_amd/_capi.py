@@ -1,0 +1,243 @@
+"""ctypes binding of include/rpe_amd.h (librpe_amd.so, HIP / gfx950).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is
+visible, loading / handle creation raises.  Nothing here imports oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librpe_amd.so")
+
+ABI_VERSION = 1
+ORB_LEVELS = 12
+PAIR_OK, PAIR_NO_DESCRIPTORS, PAIR_INSUFFICIENT_MATCHES, PAIR_NO_ESSENTIAL = 0, 1, 2, 3
+FEATURE_ORB, FEATURE_SIFT = 0, 1
+NORM_HAMMING, NORM_L2 = 0, 1
+STAGE_COUNT = 12
+
+EXPORTS = [
+    "rpe_default_config", "rpe_create", "rpe_destroy", "rpe_last_error", "rpe_device_count",
+    "rpe_keypoint_capacity", "rpe_device_malloc", "rpe_device_free", "rpe_memcpy_h2d", "rpe_memcpy_d2h",
+    "rpe_synchronize", "rpe_estimate_batch", "rpe_estimate_batch_device", "rpe_enqueue_batch_device",
+    "rpe_fetch_results", "rpe_fetch_matched_points", "rpe_orb_detect_and_compute", "rpe_orb_debug_fetch",
+    "rpe_orb_pyramid_pixels", "rpe_match_hamming", "rpe_find_essential", "rpe_recover_pose",
+    "rpe_set_profiling", "rpe_get_stage_ms", "rpe_stage_name",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("max_batch", C.c_int32), ("feature_method", C.c_int32), ("norm_type", C.c_int32),
+                ("max_matches", C.c_int32), ("nfeatures", C.c_int32), ("fast_threshold", C.c_int32),
+                ("ransac_max_iters", C.c_int32), ("ransac_prob", C.c_double), ("ransac_threshold", C.c_double)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("lx", "<i4"), ("ly", "<i4")])
+
+_lib = None
+
+
+class RpeError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen librpe_amd.so; raises (loudly) when the HIP extension is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RpeError(f"{LIB_PATH} not found: build it with __graft_entry__.build() "
+                       "(make -C relative_pose_estimation_amd/csrc); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32p = C.c_void_p, C.c_void_p
+    lib.rpe_default_config.argtypes = [C.POINTER(Config)]; lib.rpe_default_config.restype = None
+    lib.rpe_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]; lib.rpe_create.restype = C.c_int
+    lib.rpe_destroy.argtypes = [vp]; lib.rpe_destroy.restype = None
+    lib.rpe_last_error.argtypes = [vp]; lib.rpe_last_error.restype = C.c_char_p
+    lib.rpe_device_count.argtypes = []; lib.rpe_device_count.restype = C.c_int
+    lib.rpe_keypoint_capacity.argtypes = [vp]; lib.rpe_keypoint_capacity.restype = C.c_int
+    lib.rpe_device_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]; lib.rpe_device_malloc.restype = C.c_int
+    lib.rpe_device_free.argtypes = [vp, vp]; lib.rpe_device_free.restype = C.c_int
+    lib.rpe_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]; lib.rpe_memcpy_h2d.restype = C.c_int
+    lib.rpe_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]; lib.rpe_memcpy_d2h.restype = C.c_int
+    lib.rpe_synchronize.argtypes = [vp]; lib.rpe_synchronize.restype = C.c_int
+    lib.rpe_estimate_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, i32p, i32p, i32p]
+    lib.rpe_estimate_batch.restype = C.c_int
+    lib.rpe_estimate_batch_device.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, i32p, i32p, i32p]
+    lib.rpe_estimate_batch_device.restype = C.c_int
+    lib.rpe_enqueue_batch_device.argtypes = [vp, vp, vp, C.c_int, vp]; lib.rpe_enqueue_batch_device.restype = C.c_int
+    lib.rpe_fetch_results.argtypes = [vp, C.c_int, vp, vp, i32p, i32p, i32p]; lib.rpe_fetch_results.restype = C.c_int
+    lib.rpe_fetch_matched_points.argtypes = [vp, C.c_int, vp, vp]; lib.rpe_fetch_matched_points.restype = C.c_int
+    lib.rpe_orb_detect_and_compute.argtypes = [vp, vp, C.c_int, vp, vp, i32p]
+    lib.rpe_orb_detect_and_compute.restype = C.c_int
+    lib.rpe_orb_debug_fetch.argtypes = [vp, C.c_int, C.c_int, vp]; lib.rpe_orb_debug_fetch.restype = C.c_int
+    lib.rpe_orb_pyramid_pixels.argtypes = [vp]; lib.rpe_orb_pyramid_pixels.restype = C.c_int64
+    lib.rpe_match_hamming.argtypes = [vp, vp, i32p, vp, i32p, C.c_int, i32p, i32p, i32p, i32p]
+    lib.rpe_match_hamming.restype = C.c_int
+    lib.rpe_find_essential.argtypes = [vp, vp, vp, i32p, C.c_int, vp, vp, vp, i32p, i32p]
+    lib.rpe_find_essential.restype = C.c_int
+    lib.rpe_recover_pose.argtypes = [vp, vp, vp, vp, i32p, C.c_int, vp, vp, vp, i32p]
+    lib.rpe_recover_pose.restype = C.c_int
+    lib.rpe_set_profiling.argtypes = [vp, C.c_int]; lib.rpe_set_profiling.restype = C.c_int
+    lib.rpe_get_stage_ms.argtypes = [vp, vp]; lib.rpe_get_stage_ms.restype = C.c_int
+    lib.rpe_stage_name.argtypes = [C.c_int]; lib.rpe_stage_name.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One rpe_handle: one GPU, one stream, fixed image size and capacities."""
+
+    def __init__(self, width, height, max_batch=1, nfeatures=4000, max_matches=500, device=0,
+                 feature_method=FEATURE_ORB, norm_type=NORM_HAMMING, fast_threshold=15,
+                 ransac_max_iters=1000, ransac_prob=0.999, ransac_threshold=1.0):
+        self.lib = load()
+        cfg = Config()
+        self.lib.rpe_default_config(C.byref(cfg))
+        cfg.device = device; cfg.width = width; cfg.height = height; cfg.max_batch = max_batch
+        cfg.feature_method = feature_method; cfg.norm_type = norm_type
+        cfg.max_matches = max_matches; cfg.nfeatures = nfeatures; cfg.fast_threshold = fast_threshold
+        cfg.ransac_max_iters = ransac_max_iters; cfg.ransac_prob = ransac_prob; cfg.ransac_threshold = ransac_threshold
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self.lib.rpe_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise RpeError(f"rpe_create failed ({rc}): {self.lib.rpe_last_error(None).decode()}")
+        self.h = h
+        self.width, self.height, self.max_batch = width, height, max_batch
+        self.max_matches = max_matches
+        self.kcap = self.lib.rpe_keypoint_capacity(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rpe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RpeError(f"librpe_amd error {rc}: {self.lib.rpe_last_error(self.h).decode()}")
+
+    # ---- device buffers
+    def device_malloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.lib.rpe_device_malloc(self.h, nbytes, C.byref(p)))
+        return p
+
+    def device_free(self, p):
+        self._chk(self.lib.rpe_device_free(self.h, p))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.device_malloc(arr.nbytes)
+        self._chk(self.lib.rpe_memcpy_h2d(self.h, p, _p(arr), arr.nbytes))
+        return p
+
+    def synchronize(self):
+        self._chk(self.lib.rpe_synchronize(self.h))
+
+    # ---- hot path
+    def _outs(self, B):
+        return (np.zeros((B, 3, 3)), np.zeros((B, 3, 1)), np.zeros(B, np.int32), np.zeros(B, np.int32),
+                np.zeros(B, np.int32))
+
+    def estimate_batch(self, imgs1, imgs2, K):
+        imgs1 = np.ascontiguousarray(imgs1, np.uint8); imgs2 = np.ascontiguousarray(imgs2, np.uint8)
+        B = imgs1.shape[0]
+        assert imgs1.shape == imgs2.shape == (B, self.height, self.width), (imgs1.shape, imgs2.shape)
+        K = np.ascontiguousarray(K, np.float64)
+        R, t, inl, nm, st = self._outs(B)
+        self._chk(self.lib.rpe_estimate_batch(self.h, _p(imgs1), _p(imgs2), B, _p(K), _p(R), _p(t), _p(inl), _p(nm), _p(st)))
+        return R, t, inl, nm, st
+
+    def estimate_batch_device(self, d_imgs1, d_imgs2, B, K):
+        K = np.ascontiguousarray(K, np.float64)
+        R, t, inl, nm, st = self._outs(B)
+        self._chk(self.lib.rpe_estimate_batch_device(self.h, d_imgs1, d_imgs2, B, _p(K), _p(R), _p(t), _p(inl), _p(nm), _p(st)))
+        return R, t, inl, nm, st
+
+    def enqueue_batch_device(self, d_imgs1, d_imgs2, B, K):
+        K = np.ascontiguousarray(K, np.float64)
+        self._chk(self.lib.rpe_enqueue_batch_device(self.h, d_imgs1, d_imgs2, B, _p(K)))
+
+    def fetch_results(self, B):
+        R, t, inl, nm, st = self._outs(B)
+        self._chk(self.lib.rpe_fetch_results(self.h, B, _p(R), _p(t), _p(inl), _p(nm), _p(st)))
+        return R, t, inl, nm, st
+
+    def fetch_matched_points(self, B):
+        p1 = np.zeros((B, self.max_matches, 2), np.float32); p2 = np.zeros_like(p1)
+        self._chk(self.lib.rpe_fetch_matched_points(self.h, B, _p(p1), _p(p2)))
+        return p1, p2
+
+    # ---- stage API
+    def orb_detect_and_compute(self, imgs):
+        imgs = np.ascontiguousarray(imgs, np.uint8)
+        n = imgs.shape[0]
+        kps = np.zeros((n, self.kcap), KP_DTYPE); desc = np.zeros((n, self.kcap, 32), np.uint8)
+        cnt = np.zeros(n, np.int32)
+        self._chk(self.lib.rpe_orb_detect_and_compute(self.h, _p(imgs), n, _p(kps), _p(desc), _p(cnt)))
+        return kps, desc, cnt
+
+    def orb_debug_fetch(self, index, which):
+        out = np.zeros(self.lib.rpe_orb_pyramid_pixels(self.h), np.uint8)
+        self._chk(self.lib.rpe_orb_debug_fetch(self.h, index, which, _p(out)))
+        return out
+
+    def match_hamming(self, desc1, n1, desc2, n2):
+        B = len(n1)
+        d1 = np.zeros((B, self.kcap, 32), np.uint8); d2 = np.zeros_like(d1)
+        for i in range(B):
+            d1[i, :n1[i]] = desc1[i][:n1[i]]; d2[i, :n2[i]] = desc2[i][:n2[i]]
+        n1 = np.ascontiguousarray(n1, np.int32); n2 = np.ascontiguousarray(n2, np.int32)
+        mm = self.max_matches
+        q = np.zeros((B, mm), np.int32); t = np.zeros((B, mm), np.int32); d = np.zeros((B, mm), np.int32)
+        nm = np.zeros(B, np.int32)
+        self._chk(self.lib.rpe_match_hamming(self.h, _p(d1), _p(n1), _p(d2), _p(n2), B, _p(q), _p(t), _p(d), _p(nm)))
+        return q, t, d, nm
+
+    def _pack_points(self, pts1, pts2):
+        B = len(pts1)
+        mm = self.max_matches
+        p1 = np.zeros((B, mm, 2), np.float32); p2 = np.zeros_like(p1); m = np.zeros(B, np.int32)
+        for i in range(B):
+            m[i] = len(pts1[i]); p1[i, :m[i]] = pts1[i]; p2[i, :m[i]] = pts2[i]
+        return p1, p2, m
+
+    def find_essential(self, pts1, pts2, K):
+        p1, p2, m = self._pack_points(pts1, pts2)
+        B = len(m); K = np.ascontiguousarray(K, np.float64)
+        E = np.zeros((B, 3, 3)); mask = np.zeros((B, self.max_matches), np.uint8)
+        found = np.zeros(B, np.int32); info = np.zeros((B, 4), np.int32)
+        self._chk(self.lib.rpe_find_essential(self.h, _p(p1), _p(p2), _p(m), B, _p(K), _p(E), _p(mask), _p(found), _p(info)))
+        return E, mask, found, info
+
+    def recover_pose(self, E, pts1, pts2, K):
+        p1, p2, m = self._pack_points(pts1, pts2)
+        B = len(m); K = np.ascontiguousarray(K, np.float64); E = np.ascontiguousarray(E, np.float64)
+        R = np.zeros((B, 3, 3)); t = np.zeros((B, 3, 1)); inl = np.zeros(B, np.int32)
+        self._chk(self.lib.rpe_recover_pose(self.h, _p(E), _p(p1), _p(p2), _p(m), B, _p(K), _p(R), _p(t), _p(inl)))
+        return R, t, inl
+
+    # ---- profiling
+    def set_profiling(self, on):
+        self._chk(self.lib.rpe_set_profiling(self.h, 1 if on else 0))
+
+    def stage_ms(self):
+        ms = np.zeros(STAGE_COUNT, np.float32)
+        self._chk(self.lib.rpe_get_stage_ms(self.h, _p(ms)))
+        return {self.lib.rpe_stage_name(i).decode(): float(ms[i]) for i in range(STAGE_COUNT)}

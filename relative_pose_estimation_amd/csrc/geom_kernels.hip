@@ -1,0 +1,610 @@
+// geom_kernels.hip -- essential-matrix RANSAC and pose recovery on gfx950.
+//
+// Replaces cv2.findEssentialMat(pts1, pts2, K, RANSAC, 0.999, 1.0)
+// (reference src/core/pose_estimator.py:522-527) and cv2.recoverPose(E, pts1, pts2, K)
+// (:533).  Sequential OpenCV semantics (calib3d/ptsetreg.cpp RANSACPointSetRegistrator::run:
+// fixed RNG stream, "strictly more inliers wins", adaptive niters) are reproduced on a
+// parallel machine by evaluating RANSAC_CHUNK iterations at a time and replaying the
+// update rule serially over the per-model inlier counts:
+//   ransac_prepare : normalise points with K (f64), reset per-pair state
+//   ransac_solve   : one lane = one minimal sample -> Nister five-point solve (f64)
+//   ransac_score   : one workgroup per pair; lanes stride over the matches, Sampson
+//                    error (f64 -> f32 compare), wave-reduced inlier counts per model,
+//                    then lane 0 replays the sequential update rule for the chunk
+//   ransac_mask    : inlier mask of the winning model (stage API only)
+//   recover_pose   : 3x3 one-sided Jacobi SVD, 4 candidate poses, per-point 4x4 Jacobi
+//                    DLT triangulation + cheirality vote, wave-reduced counts
+// All f64 arithmetic uses the oracle's operation order (compiled with -ffp-contract=off).
+#include "rpe_internal.h"
+#include <float.h>
+
+// ------------------------------------------------ polynomial bookkeeping
+// lin: x y z 1 ; quad: x2 y2 z2 xy xz yz x y z 1 ;
+// cubic (Nister's elimination order): x3 y3 x2y xy2 x2z x2 y2z y2 xyz xy | xz2 xz x yz2 yz y z3 z2 z 1
+__device__ static const signed char LL2Q[4][4] = {{0, 3, 4, 6}, {3, 1, 5, 7}, {4, 5, 2, 8}, {6, 7, 8, 9}};
+__device__ static const signed char QL2C[10][4] = {{0, 2, 4, 5},   {3, 1, 6, 7},   {10, 13, 16, 17}, {2, 3, 8, 9},    {4, 8, 10, 11},
+                                                    {8, 6, 13, 14}, {5, 9, 11, 12}, {9, 7, 14, 15},   {11, 14, 17, 18}, {12, 15, 18, 19}};
+
+__device__ static void ll_acc(double *c, const double *a, const double *b)
+{
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) c[LL2Q[i][j]] += a[i] * b[j];
+}
+__device__ static void ql_acc(double *c, const double *a, const double *b, double s)
+{
+    for (int i = 0; i < 10; ++i) for (int j = 0; j < 4; ++j) c[QL2C[i][j]] += s * (a[i] * b[j]);
+}
+
+__device__ static double horner(const double *c, int n, double x)
+{
+    double acc = c[n];
+    for (int i = n - 1; i >= 0; --i) acc = acc * x + c[i];
+    return acc;
+}
+
+// real roots (ascending) by nested-derivative isolation + bisection to f64 resolution
+__device__ static int poly_real_roots(const double *c, int n, double *roots)
+{
+    double d[11][11];
+    double rts[2][11];
+    int nr_prev = 0, cur = 0;
+    for (int i = 0; i <= n; ++i) d[n][i] = c[i];
+    for (int k = n; k >= 2; --k)
+        for (int i = 0; i < k; ++i) d[k - 1][i] = d[k][i + 1] * (double)(i + 1);
+    rts[0][0] = -d[1][0] / d[1][1];
+    nr_prev = 1; cur = 0;
+    for (int k = 2; k <= n; ++k) {
+        const double *p = d[k];
+        const double *crit = rts[cur];
+        double *out = rts[cur ^ 1];
+        int nout = 0;
+        double mx = 0.;
+        for (int i = 0; i < k; ++i) { double a = fabs(p[i]); if (a > mx) mx = a; }
+        double R = 1. + mx / fabs(p[k]);
+        if (!(R < 1e12)) R = 1e12;
+        for (int iv = 0; iv <= nr_prev; ++iv) {
+            double a = (iv == 0) ? -R : crit[iv - 1];
+            double b = (iv == nr_prev) ? R : crit[iv];
+            if (a < -R) a = -R;
+            if (b > R) b = R;
+            if (!(a < b)) continue;
+            int sa = horner(p, k, a) > 0., sb = horner(p, k, b) > 0.;
+            if (sa == sb) continue;
+            double lo = a, hi = b;
+            for (int it = 0; it < 200; ++it) {
+                double mid = 0.5 * (lo + hi);
+                if (!(mid > lo && mid < hi)) break;
+                int sm = horner(p, k, mid) > 0.;
+                if (sm == sa) lo = mid; else hi = mid;
+            }
+            out[nout++] = 0.5 * (lo + hi);
+        }
+        nr_prev = nout; cur ^= 1;
+    }
+    for (int i = 0; i < nr_prev; ++i) roots[i] = rts[cur][i];
+    return nr_prev;
+}
+
+// Nister five-point solver (five-point.cpp EMEstimatorCallback::runKernel restated;
+// same operation order as oracle/geom_oracle.c)
+__device__ static int five_point_dev(const double *x1, const double *x2, double *E_out)
+{
+    double A[9][5];
+    for (int k = 0; k < 5; ++k) {
+        double a = x1[2 * k], b = x1[2 * k + 1], c = x2[2 * k], d = x2[2 * k + 1];
+        A[0][k] = c * a; A[1][k] = c * b; A[2][k] = c;
+        A[3][k] = d * a; A[4][k] = d * b; A[5][k] = d;
+        A[6][k] = a;     A[7][k] = b;     A[8][k] = 1.;
+    }
+    double hv[5][9], beta[5];
+    for (int k = 0; k < 5; ++k) {
+        double nrm = 0.;
+        for (int i = k; i < 9; ++i) nrm += A[i][k] * A[i][k];
+        nrm = sqrt(nrm);
+        double alpha = A[k][k] > 0. ? -nrm : nrm;
+        for (int i = 0; i < 9; ++i) hv[k][i] = 0.;
+        hv[k][k] = A[k][k] - alpha;
+        for (int i = k + 1; i < 9; ++i) hv[k][i] = A[i][k];
+        double vn = 0.;
+        for (int i = k; i < 9; ++i) vn += hv[k][i] * hv[k][i];
+        beta[k] = vn > 0. ? 2. / vn : 0.;
+        for (int j = k; j < 5; ++j) {
+            double s = 0.;
+            for (int i = k; i < 9; ++i) s += hv[k][i] * A[i][j];
+            s *= beta[k];
+            for (int i = k; i < 9; ++i) A[i][j] -= s * hv[k][i];
+        }
+    }
+    double Eb[4][9];
+    for (int m = 0; m < 4; ++m) {
+        double v[9];
+        for (int i = 0; i < 9; ++i) v[i] = 0.;
+        v[5 + m] = 1.;
+        for (int k = 4; k >= 0; --k) {
+            double s = 0.;
+            for (int i = k; i < 9; ++i) s += hv[k][i] * v[i];
+            s *= beta[k];
+            for (int i = k; i < 9; ++i) v[i] -= s * hv[k][i];
+        }
+        for (int i = 0; i < 9; ++i) Eb[m][i] = v[i];
+    }
+    double El[9][4];
+    for (int e = 0; e < 9; ++e) for (int m = 0; m < 4; ++m) El[e][m] = Eb[m][e];
+
+    double EEt[3][3][10];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int q = 0; q < 10; ++q) EEt[i][j][q] = 0.;
+    for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) {
+        for (int k = 0; k < 3; ++k) ll_acc(EEt[i][j], El[i * 3 + k], El[j * 3 + k]);
+        if (j != i) for (int q = 0; q < 10; ++q) EEt[j][i][q] = EEt[i][j][q];
+    }
+    double htr[10];
+    for (int q = 0; q < 10; ++q) htr[q] = 0.5 * ((EEt[0][0][q] + EEt[1][1][q]) + EEt[2][2][q]);
+    for (int i = 0; i < 3; ++i) for (int q = 0; q < 10; ++q) EEt[i][i][q] -= htr[q];
+
+    double Mx[10][20];
+    for (int i = 0; i < 10; ++i) for (int j = 0; j < 20; ++j) Mx[i][j] = 0.;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+        for (int k = 0; k < 3; ++k) ql_acc(Mx[i * 3 + j], EEt[i][k], El[k * 3 + j], 1.);
+    {
+        double m0[10], m1[10], m2[10], neg[4];
+        for (int q = 0; q < 10; ++q) { m0[q] = 0.; m1[q] = 0.; m2[q] = 0.; }
+        ll_acc(m0, El[4], El[8]); for (int q = 0; q < 4; ++q) neg[q] = -El[5][q]; ll_acc(m0, neg, El[7]);
+        ll_acc(m1, El[3], El[8]); ll_acc(m1, neg, El[6]);
+        ll_acc(m2, El[3], El[7]); for (int q = 0; q < 4; ++q) neg[q] = -El[4][q]; ll_acc(m2, neg, El[6]);
+        ql_acc(Mx[9], m0, El[0], 1.);
+        ql_acc(Mx[9], m1, El[1], -1.);
+        ql_acc(Mx[9], m2, El[2], 1.);
+    }
+    for (int c = 0; c < 10; ++c) {
+        int piv = c; double best = fabs(Mx[c][c]);
+        for (int r = c + 1; r < 10; ++r) { double a = fabs(Mx[r][c]); if (a > best) { best = a; piv = r; } }
+        if (best == 0.) return 0;
+        if (piv != c) for (int j = 0; j < 20; ++j) { double t = Mx[c][j]; Mx[c][j] = Mx[piv][j]; Mx[piv][j] = t; }
+        double inv = 1. / Mx[c][c];
+        for (int j = c; j < 20; ++j) Mx[c][j] *= inv;
+        for (int r = 0; r < 10; ++r) {
+            if (r == c) continue;
+            double f = Mx[r][c];
+            if (f == 0.) continue;
+            for (int j = c; j < 20; ++j) Mx[r][j] -= f * Mx[c][j];
+        }
+    }
+    double Bx[3][4], By[3][4], B1[3][5];
+    for (int i = 0; i < 3; ++i) {
+        const double *e = &Mx[4 + 2 * i][10], *f = &Mx[5 + 2 * i][10];
+        Bx[i][3] = -f[0]; Bx[i][2] = e[0] - f[1]; Bx[i][1] = e[1] - f[2]; Bx[i][0] = e[2];
+        By[i][3] = -f[3]; By[i][2] = e[3] - f[4]; By[i][1] = e[4] - f[5]; By[i][0] = e[5];
+        B1[i][4] = -f[6]; B1[i][3] = e[6] - f[7]; B1[i][2] = e[7] - f[8]; B1[i][1] = e[8] - f[9]; B1[i][0] = e[9];
+    }
+    double c10[11];
+    for (int i = 0; i < 11; ++i) c10[i] = 0.;
+    for (int i = 0; i < 3; ++i) {
+        int r0 = (i + 1) % 3, r1 = (i + 2) % 3;
+        double minor[7];
+        for (int k = 0; k < 7; ++k) minor[k] = 0.;
+        for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b)
+            minor[a + b] += Bx[r0][a] * By[r1][b] - Bx[r1][a] * By[r0][b];
+        for (int a = 0; a < 7; ++a) for (int b = 0; b < 5; ++b) c10[a + b] += minor[a] * B1[i][b];
+    }
+    int n = 10;
+    for (; n > 1; --n) if (fabs(c10[n]) > DBL_EPSILON) break;
+    double roots[10];
+    int nroots = poly_real_roots(c10, n, roots);
+    int count = 0;
+    for (int ri = 0; ri < nroots && count < 10; ++ri) {
+        double z = roots[ri];
+        double bz[3][3];
+        for (int i = 0; i < 3; ++i) {
+            bz[i][0] = ((Bx[i][3] * z + Bx[i][2]) * z + Bx[i][1]) * z + Bx[i][0];
+            bz[i][1] = ((By[i][3] * z + By[i][2]) * z + By[i][1]) * z + By[i][0];
+            bz[i][2] = (((B1[i][4] * z + B1[i][3]) * z + B1[i][2]) * z + B1[i][1]) * z + B1[i][0];
+        }
+        double bestn = -1., xv0 = 0., xv1 = 0., xv2 = 0.;
+        for (int i = 0; i < 3; ++i) {
+            int r0 = i, r1 = (i + 1) % 3;
+            double cx = bz[r0][1] * bz[r1][2] - bz[r0][2] * bz[r1][1];
+            double cy = bz[r0][2] * bz[r1][0] - bz[r0][0] * bz[r1][2];
+            double cz = bz[r0][0] * bz[r1][1] - bz[r0][1] * bz[r1][0];
+            double nn = cx * cx + cy * cy + cz * cz;
+            if (nn > bestn) { bestn = nn; xv0 = cx; xv1 = cy; xv2 = cz; }
+        }
+        if (!(bestn > 0.)) continue;
+        double inv = 1. / sqrt(bestn);
+        double w = xv2 * inv;
+        if (fabs(w) < 1e-10) continue;
+        double x = xv0 / xv2, y = xv1 / xv2;
+        double Ev[9], nrm = 0.;
+        for (int e = 0; e < 9; ++e) {
+            Ev[e] = ((Eb[0][e] * x + Eb[1][e] * y) + Eb[2][e] * z) + Eb[3][e];
+            nrm += Ev[e] * Ev[e];
+        }
+        nrm = sqrt(nrm);
+        if (!(nrm > 0.)) continue;
+        for (int e = 0; e < 9; ++e) E_out[count * 9 + e] = Ev[e] / nrm;
+        ++count;
+    }
+    return count;
+}
+
+// ---------------------------------------------------------------- prepare
+__global__ __launch_bounds__(256) void ransac_prepare_kernel(const float2 *__restrict__ pts1, const float2 *__restrict__ pts2,
+                                                              const int *__restrict__ m_n, const double *__restrict__ K,
+                                                              double2 *__restrict__ n1, double2 *__restrict__ n2,
+                                                              RpeRansacState *__restrict__ st, int *__restrict__ found,
+                                                              int max_matches, int max_iters)
+{
+    const int pair = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int M = min(m_n[pair], max_matches);
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    if (i < M) {
+        long long o = (long long)pair * max_matches + i;
+        float2 a = pts1[o], b = pts2[o];
+        n1[o] = make_double2(((double)a.x - cx) / fx, ((double)a.y - cy) / fy);
+        n2[o] = make_double2(((double)b.x - cx) / fx, ((double)b.y - cy) / fy);
+    }
+    if (i == 0) {
+        RpeRansacState s;
+        s.best_count = 0; s.best_iter = -1; s.best_model = -1;
+        s.niters = max_iters; s.next_iter = 0; s.done = (M < 5); s.found = 0; s.M = M; s.iters_run = 0; s.pad_ = 0;
+        for (int e = 0; e < 9; ++e) s.E[e] = 0.;
+        st[pair] = s;
+        found[pair] = 0;
+    }
+}
+
+// ------------------------------------------------------------------ solve
+__global__ __launch_bounds__(64) void ransac_solve_kernel(const double2 *__restrict__ n1, const double2 *__restrict__ n2,
+                                                           const RpeRansacState *__restrict__ st,
+                                                           const unsigned short *__restrict__ subsets,
+                                                           double *__restrict__ models, int *__restrict__ nmodels,
+                                                           int max_matches, int max_iters)
+{
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    const RpeRansacState s = st[pair];
+    if (s.done) return;
+    const int it = s.next_iter + lane;
+    const long long slot = (long long)pair * RPE_RANSAC_CHUNK + lane;
+    int nm = 0;
+    const bool all5 = (s.M == 5);
+    if (it < s.niters && (!all5 || it == 0)) {
+        double x1[10], x2[10];
+        const unsigned short *sub = subsets + ((long long)s.M * max_iters + it) * 5;
+        for (int k = 0; k < 5; ++k) {
+            int v = all5 ? k : (int)sub[k];
+            double2 a = n1[(long long)pair * max_matches + v], b = n2[(long long)pair * max_matches + v];
+            x1[2 * k] = a.x; x1[2 * k + 1] = a.y; x2[2 * k] = b.x; x2[2 * k + 1] = b.y;
+        }
+        double E[90];
+        nm = five_point_dev(x1, x2, E);
+        double *dst = models + slot * (RPE_MAX_MODELS * 9);
+        for (int e = 0; e < nm * 9; ++e) dst[e] = E[e];
+    }
+    nmodels[slot] = nm;
+}
+
+// ------------------------------------------------------- Sampson inlier test
+// EMEstimatorCallback::computeError + findInliers: (float)err <= (float)(thr*thr)
+__device__ __forceinline__ int sampson_inlier(const double *E, double x1, double y1, double x2, double y2, float thr2)
+{
+    double Ex0 = (E[0] * x1 + E[1] * y1) + E[2];
+    double Ex1 = (E[3] * x1 + E[4] * y1) + E[5];
+    double Ex2 = (E[6] * x1 + E[7] * y1) + E[8];
+    double Et0 = (E[0] * x2 + E[3] * y2) + E[6];
+    double Et1 = (E[1] * x2 + E[4] * y2) + E[7];
+    double x2tEx1 = (x2 * Ex0 + y2 * Ex1) + Ex2;
+    double a = Ex0 * Ex0, b = Ex1 * Ex1, c = Et0 * Et0, d = Et1 * Et1;
+    float err = (float)(x2tEx1 * x2tEx1 / (((a + b) + c) + d));
+    return err <= thr2;
+}
+
+// RANSACUpdateNumIters with log() terms tabulated on the host per (M, goodCount)
+__device__ __forceinline__ int update_niters(const double *nit_denom, const int *nit_round, double num, int M, int good, int niters)
+{
+    long long idx = (long long)M * (M + 1) / 2 + good;
+    int r = nit_round[idx];
+    if (r == -1) return 0;
+    double denom = nit_denom[idx];
+    return (denom >= 0 || -num >= niters * (-denom)) ? niters : r;
+}
+
+// ------------------------------------------------------------------ score
+__global__ __launch_bounds__(256) void ransac_score_kernel(const double2 *__restrict__ n1, const double2 *__restrict__ n2,
+                                                            RpeRansacState *__restrict__ st, const double *__restrict__ models,
+                                                            const int *__restrict__ nmodels, const double *__restrict__ K,
+                                                            const double *__restrict__ nit_denom, const int *__restrict__ nit_round,
+                                                            double nit_num, double threshold, double *__restrict__ E_out,
+                                                            int *__restrict__ found, int max_matches)
+{
+    extern __shared__ double2 s_pts[];              // [2][M]
+    __shared__ int s_counts[RPE_RANSAC_CHUNK * RPE_MAX_MODELS];
+    __shared__ int s_nm[RPE_RANSAC_CHUNK];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    RpeRansacState s = st[pair];
+    if (s.done) return;
+    const int M = s.M;
+    double2 *sp1 = s_pts, *sp2 = s_pts + max_matches;
+    for (int i = tid; i < M; i += 256) {
+        sp1[i] = n1[(long long)pair * max_matches + i];
+        sp2[i] = n2[(long long)pair * max_matches + i];
+    }
+    for (int i = tid; i < RPE_RANSAC_CHUNK * RPE_MAX_MODELS; i += 256) s_counts[i] = 0;
+    if (tid < RPE_RANSAC_CHUNK) s_nm[tid] = nmodels[(long long)pair * RPE_RANSAC_CHUNK + tid];
+    __syncthreads();
+    const double fx = K[0], fy = K[4];
+    const double thr = threshold / ((fx + fy) / 2);
+    const float thr2 = (float)(thr * thr);
+    const int kmax = min(RPE_RANSAC_CHUNK, s.niters - s.next_iter);
+    if (M > 5) {
+        for (int k = 0; k < kmax; ++k) {
+            const int nm = s_nm[k];
+            for (int m = 0; m < nm; ++m) {
+                const double *Eg = models + (((long long)pair * RPE_RANSAC_CHUNK + k) * RPE_MAX_MODELS + m) * 9;
+                double E[9];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) E[e] = Eg[e];
+                int cnt = 0;
+                for (int i = tid; i < M; i += 256) {
+                    double2 a = sp1[i], b = sp2[i];
+                    cnt += sampson_inlier(E, a.x, a.y, b.x, b.y, thr2);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+                if ((tid & 63) == 0 && cnt) atomicAdd(&s_counts[k * RPE_MAX_MODELS + m], cnt);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int best = s.best_count, niters = s.niters, bk = -1, bm = -1;
+        if (M == 5) {
+            // ptsetreg.cpp: count == modelPoints -> runKernel on all points, first model kept
+            if (s_nm[0] > 0) { best = 5; bk = 0; bm = 0; s.best_iter = 0; s.best_model = 0; }
+            niters = 1;
+            s.next_iter = 1;
+            s.iters_run = 1;
+        } else {
+            for (int k = 0; k < kmax; ++k) {
+                const int it = s.next_iter + k;
+                if (it >= niters) break;
+                s.iters_run = it + 1;
+                const int nm = s_nm[k];
+                for (int m = 0; m < nm; ++m) {
+                    int good = s_counts[k * RPE_MAX_MODELS + m];
+                    if (good > max(best, 4)) {
+                        best = good; bk = k; bm = m; s.best_iter = it; s.best_model = m;
+                        niters = update_niters(nit_denom, nit_round, nit_num, M, good, niters);
+                    }
+                }
+            }
+            s.next_iter += RPE_RANSAC_CHUNK;
+        }
+        if (bk >= 0) {
+            const double *Eg = models + (((long long)pair * RPE_RANSAC_CHUNK + bk) * RPE_MAX_MODELS + bm) * 9;
+            for (int e = 0; e < 9; ++e) { s.E[e] = Eg[e]; E_out[pair * 9 + e] = Eg[e]; }
+        }
+        s.best_count = best; s.niters = niters;
+        s.found = best > 0;
+        s.done = s.next_iter >= niters;
+        found[pair] = s.found;
+        st[pair] = s;
+    }
+}
+
+// ------------------------------------------------------------------- mask
+__global__ __launch_bounds__(256) void ransac_mask_kernel(const double2 *__restrict__ n1, const double2 *__restrict__ n2,
+                                                           const RpeRansacState *__restrict__ st, const double *__restrict__ K,
+                                                           double threshold, uint8_t *__restrict__ mask, int max_matches)
+{
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const RpeRansacState s = st[pair];
+    const double fx = K[0], fy = K[4];
+    const double thr = threshold / ((fx + fy) / 2);
+    const float thr2 = (float)(thr * thr);
+    for (int i = tid; i < max_matches; i += 256) {
+        uint8_t v = 0;
+        if (i < s.M && s.found) {
+            if (s.M == 5) v = 1;
+            else {
+                double2 a = n1[(long long)pair * max_matches + i], b = n2[(long long)pair * max_matches + i];
+                v = (uint8_t)sampson_inlier(s.E, a.x, a.y, b.x, b.y, thr2);
+            }
+        }
+        mask[(long long)pair * max_matches + i] = v;
+    }
+}
+
+void rpe_launch_ransac(rpe_handle *h, int B, bool want_mask)
+{
+    const int mm = h->cfg.max_matches, it = h->cfg.ransac_max_iters;
+    double2 *n1 = h->d_n1, *n2 = h->d_n2;
+    hipLaunchKernelGGL(ransac_prepare_kernel, dim3((mm + 255) / 256, B), dim3(256), 0, h->stream,
+                       h->d_pts1, h->d_pts2, h->d_m_n, h->d_K, n1, n2, h->d_rstate, h->d_found, mm, it);
+    const int nchunks = (it + RPE_RANSAC_CHUNK - 1) / RPE_RANSAC_CHUNK;
+    const size_t lds = sizeof(double2) * 2 * (size_t)mm;
+    for (int c = 0; c < nchunks; ++c) {
+        hipLaunchKernelGGL(ransac_solve_kernel, dim3(B), dim3(64), 0, h->stream,
+                           n1, n2, h->d_rstate, h->d_subsets, h->d_models, h->d_nmodels, mm, it);
+        hipLaunchKernelGGL(ransac_score_kernel, dim3(B), dim3(256), lds, h->stream,
+                           n1, n2, h->d_rstate, h->d_models, h->d_nmodels, h->d_K, h->d_nit_denom, h->d_nit_round,
+                           h->nit_num, h->cfg.ransac_threshold, h->d_E, h->d_found, mm);
+    }
+    if (want_mask)
+        hipLaunchKernelGGL(ransac_mask_kernel, dim3(B), dim3(256), 0, h->stream,
+                           n1, n2, h->d_rstate, h->d_K, h->cfg.ransac_threshold, h->d_mask, mm);
+}
+
+// ------------------------------------------------------------ recoverPose
+// one-sided Jacobi (Hestenes) on the columns of A (M x N row-major); V accumulates rotations.
+template <int MM, int NN>
+__device__ __forceinline__ void jacobi_cols(double *A, double *V)
+{
+    const double eps = DBL_EPSILON * 10;
+#pragma unroll
+    for (int i = 0; i < NN; ++i)
+#pragma unroll
+        for (int j = 0; j < NN; ++j) V[i * NN + j] = (i == j) ? 1. : 0.;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        int changed = 0;
+#pragma unroll
+        for (int p = 0; p < NN - 1; ++p)
+#pragma unroll
+            for (int q = p + 1; q < NN; ++q) {
+                double al = 0., be = 0., ga = 0.;
+#pragma unroll
+                for (int k = 0; k < MM; ++k) {
+                    double ap = A[k * NN + p], aq = A[k * NN + q];
+                    al += ap * ap; be += aq * aq; ga += ap * aq;
+                }
+                if (!(fabs(ga) <= eps * sqrt(al * be))) {
+                    changed = 1;
+                    double zeta = (be - al) / (2. * ga);
+                    double t = (zeta >= 0. ? 1. : -1.) / (fabs(zeta) + sqrt(1. + zeta * zeta));
+                    double c = 1. / sqrt(1. + t * t), s = c * t;
+#pragma unroll
+                    for (int k = 0; k < MM; ++k) {
+                        double ap = A[k * NN + p], aq = A[k * NN + q];
+                        A[k * NN + p] = c * ap - s * aq; A[k * NN + q] = s * ap + c * aq;
+                    }
+#pragma unroll
+                    for (int k = 0; k < NN; ++k) {
+                        double vp = V[k * NN + p], vq = V[k * NN + q];
+                        V[k * NN + p] = c * vp - s * vq; V[k * NN + q] = s * vp + c * vq;
+                    }
+                }
+            }
+        if (!changed) break;
+    }
+}
+
+__device__ __forceinline__ double det3(const double *m)
+{
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+// decomposeEssentialMat (five-point.cpp)
+__device__ static void decompose_essential(const double *E, double *R1, double *R2, double *t)
+{
+    double A[9], V[9];
+    for (int i = 0; i < 9; ++i) A[i] = E[i];
+    jacobi_cols<3, 3>(A, V);
+    double sv[3];
+    int ord[3] = {0, 1, 2};
+    for (int j = 0; j < 3; ++j) sv[j] = sqrt((A[j] * A[j] + A[3 + j] * A[3 + j]) + A[6 + j] * A[6 + j]);
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2 - i; ++j)
+        if (sv[ord[j]] < sv[ord[j + 1]]) { int tt = ord[j]; ord[j] = ord[j + 1]; ord[j + 1] = tt; }
+    double U[9], Vt[9];
+    for (int c = 0; c < 2; ++c) {
+        int j = ord[c];
+        double s = sv[j] > 0. ? 1. / sv[j] : 0.;
+        for (int r = 0; r < 3; ++r) U[r * 3 + c] = A[r * 3 + j] * s;
+    }
+    U[2] = U[3] * U[7] - U[6] * U[4];
+    U[5] = U[6] * U[1] - U[0] * U[7];
+    U[8] = U[0] * U[4] - U[3] * U[1];
+    for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) Vt[c * 3 + r] = V[r * 3 + ord[c]];
+    if (det3(U) < 0) for (int i = 0; i < 9; ++i) U[i] = -U[i];
+    if (det3(Vt) < 0) for (int i = 0; i < 9; ++i) Vt[i] = -Vt[i];
+    double UW[9], UWt[9];
+    for (int r = 0; r < 3; ++r) {
+        UW[r * 3 + 0] = -U[r * 3 + 1]; UW[r * 3 + 1] = U[r * 3 + 0]; UW[r * 3 + 2] = U[r * 3 + 2];
+        UWt[r * 3 + 0] = U[r * 3 + 1]; UWt[r * 3 + 1] = -U[r * 3 + 0]; UWt[r * 3 + 2] = U[r * 3 + 2];
+    }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+        R1[r * 3 + c] = (UW[r * 3] * Vt[c] + UW[r * 3 + 1] * Vt[3 + c]) + UW[r * 3 + 2] * Vt[6 + c];
+        R2[r * 3 + c] = (UWt[r * 3] * Vt[c] + UWt[r * 3 + 1] * Vt[3 + c]) + UWt[r * 3 + 2] * Vt[6 + c];
+    }
+    t[0] = U[2]; t[1] = U[5]; t[2] = U[8];
+}
+
+// triangulate.cpp DLT with P0 = [I|0], P = [R|t]; cheirality test of recoverPose (dist 50)
+__device__ static int cheirality_one(const double *R, const double *t, double x1, double y1, double x2, double y2)
+{
+    double A[16], V[16];
+    A[0] = -1.; A[1] = 0.;  A[2] = x1; A[3] = 0.;
+    A[4] = 0.;  A[5] = -1.; A[6] = y1; A[7] = 0.;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        A[8 + k]  = x2 * R[6 + k] - R[k];
+        A[12 + k] = y2 * R[6 + k] - R[3 + k];
+    }
+    A[11] = x2 * t[2] - t[0];
+    A[15] = y2 * t[2] - t[1];
+    jacobi_cols<4, 4>(A, V);
+    double X = 0., Y = 0., Z = 0., W = 0., best = 0.;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double nn = ((A[j] * A[j] + A[4 + j] * A[4 + j]) + A[8 + j] * A[8 + j]) + A[12 + j] * A[12 + j];
+        if (j == 0 || nn < best) { best = nn; X = V[j]; Y = V[4 + j]; Z = V[8 + j]; W = V[12 + j]; }
+    }
+    int good = (Z * W) > 0.;
+    X /= W; Y /= W; Z /= W;
+    good = good && (Z < 50.);
+    double z2 = ((R[6] * X + R[7] * Y) + R[8] * Z) + t[2];
+    good = good && (z2 > 0.) && (z2 < 50.);
+    return good;
+}
+
+__global__ __launch_bounds__(256) void recover_pose_kernel(const double *__restrict__ Eall, const float2 *__restrict__ pts1,
+                                                            const float2 *__restrict__ pts2, const int *__restrict__ m_n,
+                                                            const int *__restrict__ found, const int *__restrict__ kp_count,
+                                                            int img2_base, const double *__restrict__ K,
+                                                            double *__restrict__ Rout, double *__restrict__ tout,
+                                                            int *__restrict__ inliers, int *__restrict__ status, int max_matches)
+{
+    __shared__ int s_g[4];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int M = min(m_n[pair], max_matches);
+    int stt = RPE_PAIR_OK;
+    if (kp_count && (kp_count[pair] == 0 || kp_count[img2_base + pair] == 0)) stt = RPE_PAIR_NO_DESCRIPTORS;
+    else if (M < 5) stt = RPE_PAIR_INSUFFICIENT_MATCHES;
+    else if (found && !found[pair]) stt = RPE_PAIR_NO_ESSENTIAL;
+    if (stt != RPE_PAIR_OK) {
+        if (tid < 9) Rout[pair * 9 + tid] = (tid % 4 == 0) ? 1. : 0.;
+        if (tid < 3) tout[pair * 3 + tid] = 0.;
+        if (tid == 0) { inliers[pair] = 0; if (status) status[pair] = stt; }
+        return;
+    }
+    if (tid < 4) s_g[tid] = 0;
+    __syncthreads();
+    double E[9], R1[9], R2[9], tt[3], tn[3];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) E[e] = Eall[pair * 9 + e];
+    decompose_essential(E, R1, R2, tt);
+    tn[0] = -tt[0]; tn[1] = -tt[1]; tn[2] = -tt[2];
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    int g1 = 0, g2 = 0, g3 = 0, g4 = 0;
+    for (int i = tid; i < M; i += 256) {
+        float2 a = pts1[(long long)pair * max_matches + i], b = pts2[(long long)pair * max_matches + i];
+        double x1 = ((double)a.x - cx) / fx, y1 = ((double)a.y - cy) / fy;
+        double x2 = ((double)b.x - cx) / fx, y2 = ((double)b.y - cy) / fy;
+        g1 += cheirality_one(R1, tt, x1, y1, x2, y2);
+        g2 += cheirality_one(R2, tt, x1, y1, x2, y2);
+        g3 += cheirality_one(R1, tn, x1, y1, x2, y2);
+        g4 += cheirality_one(R2, tn, x1, y1, x2, y2);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        g1 += __shfl_xor(g1, o); g2 += __shfl_xor(g2, o); g3 += __shfl_xor(g3, o); g4 += __shfl_xor(g4, o);
+    }
+    if ((tid & 63) == 0) { atomicAdd(&s_g[0], g1); atomicAdd(&s_g[1], g2); atomicAdd(&s_g[2], g3); atomicAdd(&s_g[3], g4); }
+    __syncthreads();
+    if (tid == 0) {
+        g1 = s_g[0]; g2 = s_g[1]; g3 = s_g[2]; g4 = s_g[3];
+        const double *Rs, *ts; int g;
+        if (g1 >= g2 && g1 >= g3 && g1 >= g4)      { Rs = R1; ts = tt; g = g1; }
+        else if (g2 >= g1 && g2 >= g3 && g2 >= g4) { Rs = R2; ts = tt; g = g2; }
+        else if (g3 >= g1 && g3 >= g2 && g3 >= g4) { Rs = R1; ts = tn; g = g3; }
+        else                                        { Rs = R2; ts = tn; g = g4; }
+        for (int e = 0; e < 9; ++e) Rout[pair * 9 + e] = Rs[e];
+        for (int e = 0; e < 3; ++e) tout[pair * 3 + e] = ts[e];
+        inliers[pair] = g;
+        if (status) status[pair] = RPE_PAIR_OK;
+    }
+}
+
+void rpe_launch_pose(rpe_handle *h, int B, bool fused)
+{
+    hipLaunchKernelGGL(recover_pose_kernel, dim3(B), dim3(256), 0, h->stream,
+                       h->d_E, h->d_pts1, h->d_pts2, h->d_m_n, fused ? h->d_found : (const int *)nullptr,
+                       fused ? h->d_kp_count : (const int *)nullptr, B, h->d_K,
+                       h->d_R, h->d_t, h->d_inliers, h->d_status, h->cfg.max_matches);
+}

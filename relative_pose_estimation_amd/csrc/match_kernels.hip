@@ -1,0 +1,121 @@
+// match_kernels.hip -- brute-force Hamming matcher with OpenCV crossCheck semantics.
+//
+// Replaces cv2.BFMatcher(NORM_HAMMING, crossCheck=True).match(desc1, desc2)
+// + sorted(key=distance) + [:max_matches]   (reference src/core/pose_estimator.py:131,:144-151)
+// and the point gather of :518-519 (fused epilogue).
+//
+// One workgroup (256 lanes) per image pair.  Each lane owns one train descriptor
+// (8 dwords in VGPRs); query descriptors are staged through LDS in 1024-row tiles
+// with coalesced 16-B loads and read back as wave-uniform (broadcast) ds_read_b128;
+// distance = 8 x (v_xor_b32 + v_bcnt_u32_b32).  Selection follows
+// core/batch_distance.cpp (crosscheck=true): every train elects its nearest query
+// (strict '<', ascending query => lowest index on ties); every query keeps its best
+// elector through a packed (dist<<18 | trainIdx) LDS atomicMin (lowest train on ties).
+// The stable sort by distance is a bitonic sort of (dist<<16 | queryIdx) keys in LDS.
+#include "rpe_internal.h"
+
+#define QTILE 1024
+
+__device__ __forceinline__ int ham256(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1)
+{
+    int d = __popc(a0.x ^ b0.x);
+    d += __popc(a0.y ^ b0.y); d += __popc(a0.z ^ b0.z); d += __popc(a0.w ^ b0.w);
+    d += __popc(a1.x ^ b1.x); d += __popc(a1.y ^ b1.y); d += __popc(a1.z ^ b1.z); d += __popc(a1.w ^ b1.w);
+    return d;
+}
+
+__global__ __launch_bounds__(256) void match_hamming_kernel(const uint8_t *__restrict__ desc, const int *__restrict__ kp_count,
+                                                             const float2 *__restrict__ kp_pt, int img2_base, int kcap,
+                                                             int max_matches,
+                                                             int *__restrict__ m_q, int *__restrict__ m_t, int *__restrict__ m_d,
+                                                             int *__restrict__ m_n, float2 *__restrict__ pts1, float2 *__restrict__ pts2)
+{
+    extern __shared__ uint4 s_dyn[];
+    uint4 *s_q = s_dyn;                                   // QTILE*2 uint4 = 32 KB (later: sort keys)
+    unsigned *s_best = (unsigned *)(s_dyn + QTILE * 2);   // kcap entries
+    __shared__ int s_valid;
+    const int tid = threadIdx.x, pair = blockIdx.x;
+    const int img1 = pair, img2 = img2_base + pair;
+    const int n1 = min(kp_count[img1], kcap), n2 = min(kp_count[img2], kcap);
+    for (int i = tid; i < n1; i += 256) s_best[i] = 0xFFFFFFFFu;
+    if (tid == 0) s_valid = 0;
+    const uint4 *d1 = (const uint4 *)(desc + (long long)img1 * kcap * 32);
+    const uint4 *d2 = (const uint4 *)(desc + (long long)img2 * kcap * 32);
+    for (int tc = 0; tc < n2; tc += 256) {
+        const int j = tc + tid;
+        const bool valid = j < n2;
+        uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0;
+        if (valid) { t0 = d2[2 * j]; t1 = d2[2 * j + 1]; }
+        int bestd = 0x7FFFFFFF, besti = 0;
+        for (int qt = 0; qt < n1; qt += QTILE) {
+            const int nq = min(QTILE, n1 - qt);
+            __syncthreads();
+            for (int idx = tid; idx < nq * 2; idx += 256) s_q[idx] = d1[2 * qt + idx];
+            __syncthreads();
+            int i = 0;
+            for (; i + 4 <= nq; i += 4) {
+                int da = ham256(s_q[2 * i], s_q[2 * i + 1], t0, t1);
+                int db = ham256(s_q[2 * i + 2], s_q[2 * i + 3], t0, t1);
+                int dc = ham256(s_q[2 * i + 4], s_q[2 * i + 5], t0, t1);
+                int dd = ham256(s_q[2 * i + 6], s_q[2 * i + 7], t0, t1);
+                if (da < bestd) { bestd = da; besti = qt + i; }
+                if (db < bestd) { bestd = db; besti = qt + i + 1; }
+                if (dc < bestd) { bestd = dc; besti = qt + i + 2; }
+                if (dd < bestd) { bestd = dd; besti = qt + i + 3; }
+            }
+            for (; i < nq; ++i) {
+                int da = ham256(s_q[2 * i], s_q[2 * i + 1], t0, t1);
+                if (da < bestd) { bestd = da; besti = qt + i; }
+            }
+        }
+        if (valid && n1 > 0) atomicMin(&s_best[besti], ((unsigned)bestd << 18) | (unsigned)j);
+    }
+    __syncthreads();
+    // (dist, queryIdx) keys; unmatched queries sort to the end
+    int sortP = 64;
+    while (sortP < n1) sortP <<= 1;
+    unsigned *s_key = (unsigned *)s_q;
+    int myvalid = 0;
+    for (int i = tid; i < sortP; i += 256) {
+        unsigned key = 0xFFFFFFFFu;
+        if (i < n1) {
+            unsigned b = s_best[i];
+            if (b != 0xFFFFFFFFu) { key = ((b >> 18) << 16) | (unsigned)i; ++myvalid; }
+        }
+        s_key[i] = key;
+    }
+    if (myvalid) atomicAdd(&s_valid, myvalid);
+    __syncthreads();
+    for (int k = 2; k <= sortP; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (sortP >> 1); t += 256) {
+                int i = 2 * j * (t / j) + (t % j);
+                int ixj = i + j;
+                bool asc = (i & k) == 0;
+                unsigned a = s_key[i], b = s_key[ixj];
+                if ((a > b) == asc) { s_key[i] = b; s_key[ixj] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const int nm = min(s_valid, max_matches);
+    for (int r = tid; r < nm; r += 256) {
+        unsigned key = s_key[r];
+        int i = key & 0xFFFF, d = key >> 16;
+        int j = s_best[i] & 0x3FFFF;
+        long long o = (long long)pair * max_matches + r;
+        m_q[o] = i; m_t[o] = j; m_d[o] = d;
+        pts1[o] = kp_pt[(long long)img1 * kcap + i];
+        pts2[o] = kp_pt[(long long)img2 * kcap + j];
+    }
+    if (tid == 0) m_n[pair] = nm;
+}
+
+void rpe_launch_match(rpe_handle *h, int B)
+{
+    const int kcap = h->lay.kcap;
+    size_t lds = (size_t)QTILE * 32 + (size_t)kcap * 4;
+    hipLaunchKernelGGL(match_hamming_kernel, dim3(B), dim3(256), lds, h->stream,
+                       h->d_desc, h->d_kp_count, h->d_kp_pt, B, kcap, h->cfg.max_matches,
+                       h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
+}

@@ -1,0 +1,633 @@
+// orb_kernels.hip -- ORB detectAndCompute as hand-written gfx950 kernels.
+//
+// Replaces cv2.ORB_create(nfeatures, 1.1, 12, fastThreshold=15, HARRIS_SCORE)
+// .detectAndCompute(image, None)  (reference src/core/pose_estimator.py:85-91,:108).
+// Stages (one kernel group each, all images of the batch per launch):
+//   pyramid  : INTER_LINEAR_EXACT chain, 8.8 fixed point            (integer)
+//   fast     : FAST-9/16 score map, LDS tile + in-tile candidate compaction
+//   nms      : 3x3 NMS + 31-px border filter + per-level score histogram
+//   select   : retainBest(2*quota) threshold from the histogram, raster-ordered compaction
+//   harris   : 7x7 Harris response per candidate (f32, op order = oracle)
+//   keypoints: retainBest(quota) by radix select, raster-ordered compaction, level-major
+//   angle    : intensity-centroid moments, one wave per keypoint, fastAtan2
+//   blur     : separable fixed-point Gaussian 7x7, LDS tile
+//   describe : steered BRIEF, 32 lanes per keypoint (one descriptor byte per lane)
+// Everything is integer or mirrored-order f32, so results equal the CPU oracle bit for bit.
+#include "rpe_internal.h"
+
+#define TW 64
+#define TH 16
+
+__constant__ signed char c_pattern[256 * 4] = {
+#include "brief_pattern.inc"
+};
+__constant__ signed char c_disc[768 * 2];   // (u,v) offsets of the radius-15 disc
+__constant__ int c_ndisc;
+__constant__ signed char c_circ[16 * 2] = {0,3, 1,3, 2,2, 3,1, 3,0, 3,-1, 2,-2, 1,-3, 0,-3, -1,-3, -2,-2, -3,-1, -3,0, -3,1, -2,2, -1,3};
+
+void rpe_orb_upload_disc(const signed char *disc, int n)
+{
+    hipMemcpyToSymbol(HIP_SYMBOL(c_disc), disc, (size_t)n * 2);
+    hipMemcpyToSymbol(HIP_SYMBOL(c_ndisc), &n, sizeof(int));
+}
+
+// ---------------------------------------------------------------- pyramid
+// one thread = 4 consecutive destination pixels of level l
+__global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDeviceLayout lay, const int *__restrict__ coef, int l)
+{
+    const RpeLevel &S = lay.lv[l - 1];
+    const RpeLevel &D = lay.lv[l];
+    int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x4 >= D.pitch || y >= D.h) return;
+    uint8_t *base = pyr + (long long)blockIdx.z * lay.stride;
+    const uint8_t *src = base + S.off;
+    const int *xo = coef + D.coef_off, *xa = xo + D.w, *yo = xa + D.w, *ya = yo + D.h;
+    int oy = yo[y], b1 = ya[y], b0 = 256 - b1;
+    int oy1 = min(oy + 1, S.h - 1);
+    const uint8_t *r0 = src + (long long)oy * S.pitch, *r1 = src + (long long)oy1 * S.pitch;
+    unsigned out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int x = x4 + j;
+        unsigned v = 0;
+        if (x < D.w) {
+            int o = xo[x], a1 = xa[x], a0 = 256 - a1;
+            int o1 = min(o + 1, S.w - 1);
+            unsigned h0 = (unsigned)(a0 * r0[o] + a1 * r0[o1]);
+            unsigned h1 = (unsigned)(a0 * r1[o] + a1 * r1[o1]);
+            v = ((unsigned)b0 * h0 + (unsigned)b1 * h1 + 32768u) >> 16;
+        }
+        out |= v << (8 * j);
+    }
+    *(unsigned *)(base + D.off + (long long)y * D.pitch + x4) = out;
+}
+
+void rpe_launch_pyramid(rpe_handle *h, int n_img)
+{
+    for (int l = 1; l < RPE_NLEVELS; ++l) {
+        const RpeLevel &D = h->lay.lv[l];
+        dim3 grid((D.pitch / 4 + 63) / 64, (D.h + 3) / 4, n_img);
+        hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, h->stream, h->d_pyr, h->lay, h->d_coef, l);
+    }
+}
+
+// ------------------------------------------------------------------- FAST
+// Tile 64x16 pixels; LDS input tile 22 rows x 72 bytes (halo 3 rows, 4 columns for
+// dword alignment).  Phase 1: 4 pixels per thread, compass quick test, survivors
+// appended to an LDS candidate list.  Phase 2: the list is processed densely
+// (one candidate per thread per trip): 16 ring differences, window-9 min/max via
+// min3/max3, score = max(A, B) - 1 written to an LDS output tile.
+__device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
+__device__ __forceinline__ int imax3(int a, int b, int c) { return max(a, max(b, c)); }
+
+__global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ score,
+                                                          RpeDeviceLayout lay, const RpeTile *__restrict__ tiles)
+{
+    __shared__ unsigned s_in[22 * 18];
+    __shared__ unsigned s_out[TH * 16];
+    __shared__ unsigned short s_cand[TW * TH];
+    __shared__ int s_ncand;
+    const int tid = threadIdx.x;
+    const RpeTile t = tiles[blockIdx.x];
+    const RpeLevel &L = lay.lv[t.level];
+    const int w = L.w, hgt = L.h, pitch = L.pitch, thr = lay.fast_thr;
+    const int x0 = t.tx, y0 = t.ty;
+    const long long ibase = (long long)blockIdx.y * lay.stride + L.off;
+    const uint8_t *src = pyr + ibase;
+    if (tid == 0) s_ncand = 0;
+    for (int i = tid; i < 22 * 18; i += 256) {
+        int r = i / 18, c = i - r * 18;
+        int y = min(max(y0 - 3 + r, 0), hgt - 1);
+        int x = min(max(x0 - 4 + 4 * c, 0), pitch - 4);
+        s_in[i] = *(const unsigned *)(src + (long long)y * pitch + x);
+    }
+    s_out[tid] = 0;
+    __syncthreads();
+    {
+        const int tx = tid & 15, ty = tid >> 4;
+        const int r = ty + 3;
+        unsigned cdw = s_in[r * 18 + tx + 1], ldw = s_in[r * 18 + tx], rdw = s_in[r * 18 + tx + 2];
+        unsigned top = s_in[(r - 3) * 18 + tx + 1], bot = s_in[(r + 3) * 18 + tx + 1];
+        unsigned long long lo64 = (unsigned long long)ldw | ((unsigned long long)cdw << 32);
+        unsigned long long hi64 = (unsigned long long)cdw | ((unsigned long long)rdw << 32);
+        const int py = y0 + ty;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int px = x0 + 4 * tx + j;
+            int v = (cdw >> (8 * j)) & 255;
+            int d0 = v - (int)((bot >> (8 * j)) & 255);
+            int d8 = v - (int)((top >> (8 * j)) & 255);
+            int d4 = v - (int)((hi64 >> (8 * (3 + j))) & 255);
+            int d12 = v - (int)((lo64 >> (8 * (1 + j))) & 255);
+            bool skip = (abs(d0) <= thr && abs(d8) <= thr) || (abs(d4) <= thr && abs(d12) <= thr);
+            bool valid = px >= 3 && px < w - 3 && py >= 3 && py < hgt - 3;
+            if (valid && !skip) {
+                int idx = atomicAdd(&s_ncand, 1);
+                s_cand[idx] = (unsigned short)((ty << 6) | (4 * tx + j));
+            }
+        }
+    }
+    __syncthreads();
+    const int ncand = s_ncand;
+    const uint8_t *sb = (const uint8_t *)s_in;
+    for (int i = tid; i < ncand; i += 256) {
+        int c = s_cand[i];
+        int lx = c & 63, ly = c >> 6;
+        const uint8_t *p = sb + (ly + 3) * 72 + lx + 4;
+        int v = p[0];
+        int d[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k] = v - (int)p[(int)c_circ[2 * k + 1] * 72 + (int)c_circ[2 * k]];
+        int m3[16], x3[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            m3[k] = imin3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+            x3[k] = imax3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        }
+        int A = -1000, Bm = 1000;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            A = max(A, imin3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]));
+            Bm = min(Bm, imax3(x3[k], x3[(k + 3) & 15], x3[(k + 6) & 15]));
+        }
+        int s = max(A, -Bm);
+        if (s > thr) ((uint8_t *)s_out)[ly * 64 + lx] = (uint8_t)(s - 1);
+    }
+    __syncthreads();
+    {
+        const int tx = tid & 15, ty = tid >> 4;
+        int px = x0 + 4 * tx, py = y0 + ty;
+        if (py < hgt && px < pitch)
+            *(unsigned *)(score + ibase + (long long)py * pitch + px) = s_out[tid];
+    }
+}
+
+void rpe_launch_fast(rpe_handle *h, int n_img)
+{
+    hipLaunchKernelGGL(fast_score_kernel, dim3(h->n_tiles_fast, n_img), dim3(256), 0, h->stream,
+                       h->d_pyr, h->d_bufA, h->lay, h->d_tiles_fast);
+}
+
+// -------------------------------------------------------------------- NMS
+// 3x3 strict-maximum suppression on the score map, 31-px border filter, and a
+// 256-bin histogram of the surviving scores per (image, level).
+__global__ __launch_bounds__(256) void nms_hist_kernel(const uint8_t *__restrict__ score, uint8_t *__restrict__ nms,
+                                                        unsigned *__restrict__ hist, RpeDeviceLayout lay,
+                                                        const RpeTile *__restrict__ tiles)
+{
+    __shared__ unsigned s_in[18 * 18];
+    __shared__ unsigned s_hist[256];
+    const int tid = threadIdx.x;
+    const RpeTile t = tiles[blockIdx.x];
+    const RpeLevel &L = lay.lv[t.level];
+    const int w = L.w, hgt = L.h, pitch = L.pitch;
+    const int x0 = t.tx, y0 = t.ty;
+    const long long ibase = (long long)blockIdx.y * lay.stride + L.off;
+    const uint8_t *src = score + ibase;
+    s_hist[tid] = 0;
+    for (int i = tid; i < 18 * 18; i += 256) {
+        int r = i / 18, c = i - r * 18;
+        int y = min(max(y0 - 1 + r, 0), hgt - 1);
+        int x = min(max(x0 - 4 + 4 * c, 0), pitch - 4);
+        s_in[i] = *(const unsigned *)(src + (long long)y * pitch + x);
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    const int py = y0 + ty;
+    unsigned out = 0;
+    if (py >= RPE_EDGE && py < hgt - RPE_EDGE) {
+        unsigned long long rows[3][2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            unsigned a = s_in[(ty + r) * 18 + tx], b = s_in[(ty + r) * 18 + tx + 1], c = s_in[(ty + r) * 18 + tx + 2];
+            rows[r][0] = (unsigned long long)a | ((unsigned long long)b << 32);   // bytes x-4 .. x+3
+            rows[r][1] = (unsigned long long)b | ((unsigned long long)c << 32);   // bytes x .. x+7
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int px = x0 + 4 * tx + j;
+            int v = (int)((rows[1][1] >> (8 * j)) & 255);
+            if (v == 0 || px < RPE_EDGE || px >= w - RPE_EDGE) continue;
+            bool keep = true;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                int lft = (int)((rows[r][0] >> (8 * (3 + j))) & 255);
+                int mid = (int)((rows[r][1] >> (8 * j)) & 255);
+                int rgt = (int)((rows[r][1] >> (8 * (j + 1))) & 255);
+                keep = keep && v > lft && v > rgt && (r == 1 || v > mid);
+            }
+            if (keep) { out |= (unsigned)v << (8 * j); atomicAdd(&s_hist[v], 1u); }
+        }
+    }
+    int px = x0 + 4 * tx;
+    if (py < hgt && px < pitch) *(unsigned *)(nms + ibase + (long long)py * pitch + px) = out;
+    __syncthreads();
+    unsigned c = s_hist[tid];
+    if (c) atomicAdd(&hist[((long long)blockIdx.y * RPE_NLEVELS + t.level) * 256 + tid], c);
+}
+
+void rpe_launch_nms(rpe_handle *h, int n_img)
+{
+    hipMemsetAsync(h->d_hist, 0, sizeof(unsigned) * 256 * RPE_NLEVELS * (size_t)n_img, h->stream);
+    hipLaunchKernelGGL(nms_hist_kernel, dim3(h->n_tiles_full, n_img), dim3(256), 0, h->stream,
+                       h->d_bufA, h->d_bufB, h->d_hist, h->lay, h->d_tiles_full);
+}
+
+// ------------------------------------------------- block-wide exclusive scan
+__device__ __forceinline__ int block_excl_scan(int v, int *s_wave /*[5]*/, int &total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(inc, o); if (lane >= o) inc += n; }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { int s = s_wave[k]; if (k < wv) base += s; }
+    total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+// ----------------------------------------------------------------- select
+// KeyPointsFilter::retainBest(2*quota) on the FAST score: threshold = score of
+// the (2q)-th best keypoint, ties kept.  One workgroup per (image, level) scans
+// the NMS map linearly (raster order) and compacts survivors in that order.
+__global__ __launch_bounds__(256) void select_candidates_kernel(const uint8_t *__restrict__ nms, const unsigned *__restrict__ hist,
+                                                                 unsigned *__restrict__ cand_xy, int *__restrict__ cand_count,
+                                                                 RpeDeviceLayout lay)
+{
+    __shared__ int s_wave[5];
+    __shared__ int s_tau;
+    const int tid = threadIdx.x, l = blockIdx.x, img = blockIdx.y;
+    const RpeLevel &L = lay.lv[l];
+    const unsigned *hg = hist + ((long long)img * RPE_NLEVELS + l) * 256;
+    if (tid < 64) {
+        // wave 0: suffix sums over 256 bins, 4 bins per lane (descending)
+        int b0 = 255 - 4 * tid;
+        int c0 = hg[b0], c1 = hg[b0 - 1], c2 = hg[b0 - 2], c3 = hg[b0 - 3];
+        int s = c0 + c1 + c2 + c3, inc = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(inc, o); if (tid >= o) inc += n; }
+        int total = __shfl(inc, 63);
+        int n2 = 2 * L.quota;
+        int before = inc - s;
+        // first bin (descending) where cumulative >= n2
+        int tau = -1;
+        if (before < n2 && inc >= n2) {
+            int a = before + c0;
+            if (a >= n2) tau = b0; else { a += c1; if (a >= n2) tau = b0 - 1; else { a += c2; tau = (a >= n2) ? b0 - 2 : b0 - 3; } }
+        }
+        unsigned long long m = __ballot(tau >= 0);
+        int src_lane = m ? (__ffsll((long long)m) - 1) : 0;
+        int t = __shfl(tau, src_lane);
+        if (tid == 0) s_tau = (total > n2 && m) ? max(t, 1) : 1;
+    }
+    __syncthreads();
+    const int tau = s_tau;
+    const uint8_t *src = nms + (long long)img * lay.stride + L.off;
+    const int nbytes = L.pitch * L.h;
+    const int ccap = L.ccap;
+    unsigned *out = cand_xy + (long long)img * lay.cand_total + L.cand_off;
+    int base = 0;
+    for (int c0 = 0; c0 < nbytes; c0 += 4096) {
+        int pos = c0 + tid * 16;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (pos < nbytes) v = *(const uint4 *)(src + pos);
+        unsigned wds[4] = {v.x, v.y, v.z, v.w};
+        int cnt = 0;
+        if ((v.x | v.y | v.z | v.w) != 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cnt += (int)((wds[k >> 2] >> (8 * (k & 3))) & 255) >= tau;
+        }
+        int total;
+        int ex = block_excl_scan(cnt, s_wave, total);
+        if (cnt) {
+            int o = base + ex;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                int b = (int)((wds[k >> 2] >> (8 * (k & 3))) & 255);
+                if (b >= tau) {
+                    if (o < ccap) { int p = pos + k; int y = p / L.pitch; int x = p - y * L.pitch; out[o] = ((unsigned)y << 16) | (unsigned)x; }
+                    ++o;
+                }
+            }
+        }
+        base += total;
+    }
+    if (tid == 0) cand_count[img * RPE_NLEVELS + l] = min(base, ccap);
+}
+
+void rpe_launch_select(rpe_handle *h, int n_img)
+{
+    hipLaunchKernelGGL(select_candidates_kernel, dim3(RPE_NLEVELS, n_img), dim3(256), 0, h->stream,
+                       h->d_bufB, h->d_hist, h->d_cand_xy, h->d_cand_count, h->lay);
+}
+
+// ----------------------------------------------------------------- harris
+// orb.cpp HarrisResponses: 7x7 block of 3x3 Sobel-like derivatives, f32 response.
+__global__ __launch_bounds__(256) void harris_kernel(const uint8_t *__restrict__ pyr, const unsigned *__restrict__ cand_xy,
+                                                      const int *__restrict__ cand_count, float *__restrict__ cand_resp,
+                                                      RpeDeviceLayout lay)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
+    if (c >= lay.cand_total) return;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < RPE_NLEVELS; ++k) if (c >= lay.lv[k].cand_off) l = k;
+    const RpeLevel &L = lay.lv[l];
+    const int ci = c - L.cand_off;
+    if (ci >= cand_count[img * RPE_NLEVELS + l]) return;
+    unsigned xy = cand_xy[(long long)img * lay.cand_total + c];
+    const int x0 = xy & 0xFFFF, y0 = xy >> 16, pitch = L.pitch;
+    const uint8_t *p0 = pyr + (long long)img * lay.stride + L.off + (long long)(y0 - 4) * pitch + (x0 - 4);
+    int a = 0, b = 0, cc = 0;
+    int rowm[9], row0[9], rowp[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { rowm[k] = p0[k]; row0[k] = p0[pitch + k]; }
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const uint8_t *pr = p0 + (long long)(r + 2) * pitch;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rowp[k] = pr[k];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            int Ix = (row0[k + 1] - row0[k - 1]) * 2 + (rowm[k + 1] - rowm[k - 1]) + (rowp[k + 1] - rowp[k - 1]);
+            int Iy = (rowp[k] - rowm[k]) * 2 + (rowp[k - 1] - rowm[k - 1]) + (rowp[k + 1] - rowm[k + 1]);
+            a += Ix * Ix; b += Iy * Iy; cc += Ix * Iy;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { rowm[k] = row0[k]; row0[k] = rowp[k]; }
+    }
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    const float scale_sq_sq = scale * scale * scale * scale;
+    float fa = (float)a, fb = (float)b, fc = (float)cc;
+    float t1 = fa * fb, t2 = fc * fc, t3 = t1 - t2;
+    float s = fa + fb;
+    float t4 = (0.04f * s) * s;
+    cand_resp[(long long)img * lay.cand_total + c] = (t3 - t4) * scale_sq_sq;
+}
+
+void rpe_launch_harris(rpe_handle *h, int n_img)
+{
+    hipLaunchKernelGGL(harris_kernel, dim3((h->lay.cand_total + 255) / 256, n_img), dim3(256), 0, h->stream,
+                       h->d_pyr, h->d_cand_xy, h->d_cand_count, h->d_cand_resp, h->lay);
+}
+
+// -------------------------------------------------------------- keypoints
+// KeyPointsFilter::retainBest(quota) on the Harris response per level (radix
+// select of the quota-th largest f32, ties kept), ordered compaction into the
+// final level-major / raster-ordered keypoint list.  One workgroup per image.
+__device__ __forceinline__ unsigned float_key(float f)
+{
+    unsigned u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void select_keypoints_kernel(const unsigned *__restrict__ cand_xy, const float *__restrict__ cand_resp,
+                                                                const int *__restrict__ cand_count,
+                                                                unsigned *__restrict__ kp_xy, float *__restrict__ kp_resp,
+                                                                float2 *__restrict__ kp_pt, int *__restrict__ kp_count,
+                                                                RpeDeviceLayout lay)
+{
+    __shared__ unsigned s_hist[256];
+    __shared__ int s_wave[5];
+    __shared__ unsigned s_prefix;
+    __shared__ int s_kk;
+    const int tid = threadIdx.x, img = blockIdx.x;
+    const int kcap = lay.kcap;
+    int offset = 0;
+    for (int l = 0; l < RPE_NLEVELS; ++l) {
+        const RpeLevel &L = lay.lv[l];
+        const int n = cand_count[img * RPE_NLEVELS + l];
+        const int q = L.quota;
+        const float *resp = cand_resp + (long long)img * lay.cand_total + L.cand_off;
+        const unsigned *xy = cand_xy + (long long)img * lay.cand_total + L.cand_off;
+        unsigned thr_key = 0;
+        if (n > q) {
+            unsigned prefix = 0, mask = 0;
+            if (tid == 0) s_kk = q;
+            for (int pass = 3; pass >= 0; --pass) {
+                const int shift = 8 * pass;
+                s_hist[tid] = 0;
+                __syncthreads();
+                for (int i = tid; i < n; i += 256) {
+                    unsigned key = float_key(resp[i]);
+                    if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255], 1u);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int kk = s_kk, acc = 0, bin = 0;
+                    for (int b = 255; b >= 0; --b) {
+                        int c = (int)s_hist[b];
+                        if (acc + c >= kk) { bin = b; break; }
+                        acc += c;
+                    }
+                    s_kk = kk - acc;
+                    s_prefix = prefix | ((unsigned)bin << shift);
+                }
+                __syncthreads();
+                prefix = s_prefix;
+                mask |= 255u << shift;
+            }
+            thr_key = prefix;
+        }
+        for (int c0 = 0; c0 < n; c0 += 256) {
+            int i = c0 + tid;
+            float r = 0.f; bool keep = false;
+            if (i < n) { r = resp[i]; keep = float_key(r) >= thr_key; }
+            int total;
+            int ex = block_excl_scan(keep ? 1 : 0, s_wave, total);
+            if (keep) {
+                int o = offset + ex;
+                if (o < kcap) {
+                    unsigned p = xy[i];
+                    int x = p & 0xFFFF, y = p >> 16;
+                    long long g = (long long)img * kcap + o;
+                    kp_xy[g] = (unsigned)x | ((unsigned)y << 12) | ((unsigned)l << 24);
+                    kp_resp[g] = r;
+                    kp_pt[g] = make_float2((float)x * L.scale, (float)y * L.scale);
+                }
+            }
+            offset += total;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) kp_count[img] = min(offset, kcap);
+}
+
+void rpe_launch_keypoints(rpe_handle *h, int n_img)
+{
+    hipLaunchKernelGGL(select_keypoints_kernel, dim3(n_img), dim3(256), 0, h->stream,
+                       h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_pt,
+                       h->d_kp_count, h->lay);
+}
+
+// ------------------------------------------------------------------ angle
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float scale = (float)(180.0 / 3.141592653589793238462643383279502884);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// orb.cpp ICAngles: one wave per keypoint, lanes stride over the 749 disc pixels,
+// integer moments reduced with wave shuffles.
+__global__ __launch_bounds__(256) void ic_angle_kernel(const uint8_t *__restrict__ pyr, const unsigned *__restrict__ kp_xy,
+                                                        const int *__restrict__ kp_count, float *__restrict__ kp_angle,
+                                                        RpeDeviceLayout lay)
+{
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), img = blockIdx.y;
+    if (k >= kp_count[img]) return;
+    unsigned p = kp_xy[(long long)img * lay.kcap + k];
+    const int x0 = p & 0xFFF, y0 = (p >> 12) & 0xFFF, l = p >> 24;
+    const RpeLevel &L = lay.lv[l];
+    const uint8_t *c = pyr + (long long)img * lay.stride + L.off + (long long)y0 * L.pitch + x0;
+    int m10 = 0, m01 = 0;
+    const int nd = c_ndisc;
+    for (int i = lane; i < nd; i += 64) {
+        int u = c_disc[2 * i], v = c_disc[2 * i + 1];
+        int val = c[v * L.pitch + u];
+        m10 += u * val; m01 += v * val;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    if (lane == 0) kp_angle[(long long)img * lay.kcap + k] = fast_atan2_deg((float)m01, (float)m10);
+}
+
+void rpe_launch_angle(rpe_handle *h, int n_img)
+{
+    hipLaunchKernelGGL(ic_angle_kernel, dim3((h->lay.kcap + 3) / 4, n_img), dim3(256), 0, h->stream,
+                       h->d_pyr, h->d_kp_xy, h->d_kp_count, h->d_kp_angle, h->lay);
+}
+
+// ------------------------------------------------------------------- blur
+// GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101), 8.8 fixed-point separable
+// kernel [18,34,48,56,48,34,18]; result (sum + 2^15) >> 16.
+__device__ __forceinline__ int refl101(int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * n - 2 - p : p; }
+
+__global__ __launch_bounds__(256) void blur_kernel(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ dst,
+                                                    RpeDeviceLayout lay, const RpeTile *__restrict__ tiles)
+{
+    __shared__ uint8_t s_in[22 * 72];
+    __shared__ unsigned short s_h[22 * 64];
+    const int tid = threadIdx.x;
+    const RpeTile t = tiles[blockIdx.x];
+    const RpeLevel &L = lay.lv[t.level];
+    const int w = L.w, hgt = L.h, pitch = L.pitch;
+    const int x0 = t.tx, y0 = t.ty;
+    const long long ibase = (long long)blockIdx.y * lay.stride + L.off;
+    const uint8_t *src = pyr + ibase;
+    for (int i = tid; i < 22 * 70; i += 256) {
+        int r = i / 70, c = i - r * 70;
+        int y = refl101(y0 - 3 + r, hgt), x = refl101(x0 - 3 + c, w);
+        y = min(max(y, 0), hgt - 1); x = min(max(x, 0), w - 1);
+        s_in[r * 72 + c] = src[(long long)y * pitch + x];
+    }
+    __syncthreads();
+    for (int i = tid; i < 22 * 64; i += 256) {
+        int r = i >> 6, c = i & 63;
+        const uint8_t *p = s_in + r * 72 + c;
+        unsigned s = 18u * p[0] + 34u * p[1] + 48u * p[2] + 56u * p[3] + 48u * p[4] + 34u * p[5] + 18u * p[6];
+        s_h[i] = (unsigned short)s;
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    unsigned out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned short *p = s_h + ty * 64 + 4 * tx + j;
+        unsigned s = 18u * p[0] + 34u * p[64] + 48u * p[128] + 56u * p[192] + 48u * p[256] + 34u * p[320] + 18u * p[384];
+        out |= ((s + 32768u) >> 16) << (8 * j);
+    }
+    int px = x0 + 4 * tx, py = y0 + ty;
+    if (py < hgt && px < pitch) *(unsigned *)(dst + ibase + (long long)py * pitch + px) = out;
+}
+
+void rpe_launch_blur(rpe_handle *h, int n_img)
+{
+    hipLaunchKernelGGL(blur_kernel, dim3(h->n_tiles_full, n_img), dim3(256), 0, h->stream,
+                       h->d_pyr, h->d_bufA, h->lay, h->d_tiles_full);
+}
+
+// --------------------------------------------------------------- describe
+// deterministic sin/cos (fdlibm kernel polynomials); identical op order to the oracle
+__device__ __forceinline__ void det_sincos(double x, double &sn, double &cs)
+{
+    const double PIO2_HI = 1.57079632673412561417e+00, PIO2_LO = 6.07710050650619224932e-11;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    int k = (int)(x * 0.63661977236758134308 + 0.5);
+    double r = (x - (double)k * PIO2_HI) - (double)k * PIO2_LO;
+    double z = r * r;
+    double ps = S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))));
+    double pc = C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6))));
+    double s = r + (r * z) * ps;
+    double c = (1.0 - 0.5 * z) + (z * z) * pc;
+    switch (k & 3) {
+    case 0: sn = s;  cs = c;  break;
+    case 1: sn = c;  cs = -s; break;
+    case 2: sn = -s; cs = -c; break;
+    default: sn = -c; cs = s; break;
+    }
+}
+
+// orb.cpp computeOrbDescriptors (WTA_K = 2): 32 lanes per keypoint, lane = byte index.
+__global__ __launch_bounds__(256) void describe_kernel(const uint8_t *__restrict__ blur, const unsigned *__restrict__ kp_xy,
+                                                        const float2 *__restrict__ kp_pt, const float *__restrict__ kp_angle,
+                                                        const int *__restrict__ kp_count, uint8_t *__restrict__ desc,
+                                                        RpeDeviceLayout lay)
+{
+    const int byte = threadIdx.x & 31;
+    const int k = blockIdx.x * 8 + (threadIdx.x >> 5), img = blockIdx.y;
+    if (k >= kp_count[img]) return;
+    const long long g = (long long)img * lay.kcap + k;
+    const int l = kp_xy[g] >> 24;
+    const RpeLevel &L = lay.lv[l];
+    const float2 pt = kp_pt[g];
+    const float sc = 1.f / L.scale;
+    const float ang = kp_angle[g] * (float)(3.141592653589793238462643383279502884 / 180.0);
+    double sn, cs;
+    det_sincos((double)ang, sn, cs);
+    const float a = (float)cs, b = (float)sn;
+    const int cx = __float2int_rn(pt.x * sc), cy = __float2int_rn(pt.y * sc);
+    const int pitch = L.pitch;
+    const uint8_t *center = blur + (long long)img * lay.stride + L.off + (long long)cy * pitch + cx;
+    int val = 0;
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+        const signed char *p = c_pattern + 4 * (byte * 8 + bit);
+        float p0 = (float)p[0], p1 = (float)p[1], p2 = (float)p[2], p3 = (float)p[3];
+        float x0 = p0 * a - p1 * b, y0 = p0 * b + p1 * a;
+        float x1 = p2 * a - p3 * b, y1 = p2 * b + p3 * a;
+        int t0 = center[__float2int_rn(y0) * pitch + __float2int_rn(x0)];
+        int t1 = center[__float2int_rn(y1) * pitch + __float2int_rn(x1)];
+        val |= (t0 < t1) << bit;
+    }
+    desc[g * 32 + byte] = (uint8_t)val;
+}
+
+void rpe_launch_describe(rpe_handle *h, int n_img)
+{
+    hipLaunchKernelGGL(describe_kernel, dim3((h->lay.kcap + 7) / 8, n_img), dim3(256), 0, h->stream,
+                       h->d_bufA, h->d_kp_xy, h->d_kp_pt, h->d_kp_angle, h->d_kp_count, h->d_desc, h->lay);
+}

@@ -1,0 +1,609 @@
+// rpe_api.hip -- host side of the C-ABI (include/rpe_amd.h): handle lifecycle,
+// HBM workspace, host-built tables (pyramid geometry, resize coefficients,
+// RANSAC subset stream and niters table) and stage orchestration on one HIP stream.
+#include "rpe_internal.h"
+#include <math.h>
+#include <float.h>
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+void rpe_orb_upload_disc(const signed char *disc, int n);
+
+static std::string g_create_err;
+
+#define HIPCHK(h, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            char b_[512];                                                                       \
+            snprintf(b_, sizeof(b_), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            if (h) (h)->err = b_; else g_create_err = b_;                                       \
+            return RPE_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+static int cv_round(double v) { return (int)lrint(v); }
+static long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
+
+extern "C" void rpe_default_config(rpe_config *c)
+{
+    memset(c, 0, sizeof(*c));
+    c->abi_version = RPE_ABI_VERSION;
+    c->device = 0;
+    c->width = 640; c->height = 480;
+    c->max_batch = 1;
+    c->feature_method = RPE_FEATURE_ORB;   // pose_estimator.py:22
+    c->norm_type = RPE_NORM_HAMMING;       // pose_estimator.py:23
+    c->max_matches = 500;                  // pose_estimator.py:24
+    c->nfeatures = 4000;                   // pose_estimator.py:25
+    c->fast_threshold = 15;                // pose_estimator.py:89
+    c->ransac_max_iters = 1000;
+    c->ransac_prob = 0.999;                // pose_estimator.py:525
+    c->ransac_threshold = 1.0;             // pose_estimator.py:526
+}
+
+extern "C" int rpe_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char *rpe_last_error(const rpe_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+extern "C" int rpe_keypoint_capacity(const rpe_handle *h) { return h ? h->lay.kcap : 0; }
+
+// ORB pyramid geometry (orb.cpp): scale_l = (float)pow(1.1f, l), size cvRound(dim/scale),
+// per-level quota from the geometric series, remainder to the last level.
+static void build_layout(rpe_handle *h)
+{
+    RpeDeviceLayout &L = h->lay;
+    const int W = h->cfg.width, H = h->cfg.height, nf = h->cfg.nfeatures;
+    const double sf = (double)1.1f;
+    long long off = 0;
+    int coef = 0, cand = 0;
+    for (int l = 0; l < RPE_NLEVELS; ++l) {
+        RpeLevel &v = L.lv[l];
+        v.scale = (float)pow(sf, (double)l);
+        v.w = cv_round((double)((float)W / v.scale));
+        v.h = cv_round((double)((float)H / v.scale));
+        v.pitch = (int)align_up(v.w, 16);
+        v.off = off;
+        off = align_up(off + (long long)v.pitch * v.h, 256);
+        v.coef_off = coef;
+        coef += 2 * (v.w + v.h);
+    }
+    L.stride = off;
+    float factor = (float)(1.0 / sf);
+    float nd = nf * (1 - factor) / (1 - (float)pow((double)factor, (double)RPE_NLEVELS));
+    int sum = 0;
+    for (int l = 0; l < RPE_NLEVELS - 1; ++l) {
+        L.lv[l].quota = cv_round((double)nd);
+        sum += L.lv[l].quota;
+        nd *= factor;
+    }
+    L.lv[RPE_NLEVELS - 1].quota = nf - sum > 0 ? nf - sum : 0;
+    for (int l = 0; l < RPE_NLEVELS; ++l) {
+        L.lv[l].ccap = 4 * L.lv[l].quota + 256;
+        L.lv[l].cand_off = cand;
+        cand += L.lv[l].ccap;
+    }
+    L.cand_total = cand;
+    L.kcap = nf + 64;
+    L.fast_thr = h->cfg.fast_threshold;
+}
+
+// INTER_LINEAR_EXACT coefficients (resize.cpp interpolationLinear<ufixedpoint16>)
+static void lin_coeffs(int src, int dst, int *ofs, int *a1)
+{
+    double inv_scale = (double)dst / (double)src;
+    double scale = 1.0 / inv_scale;
+    for (int d = 0; d < dst; ++d) {
+        double f = scale * ((double)d + 0.5) - 0.5;
+        int i = (int)floor(f);
+        if (i >= 0 && src > 1) {
+            if (i < src - 1) { ofs[d] = i; a1[d] = cv_round((f - (double)i) * 256.0); }
+            else { ofs[d] = src - 1; a1[d] = 0; }
+        } else { ofs[d] = 0; a1[d] = 0; }
+    }
+}
+
+// cv::RNG (core/rand.cpp) MWC generator, used by RANSAC's getSubset
+static inline uint32_t rng_next(uint64_t &st)
+{
+    st = (uint64_t)(uint32_t)st * 4164903690ULL + (uint32_t)(st >> 32);
+    return (uint32_t)st;
+}
+
+template <typename T>
+static int dmalloc(rpe_handle *h, T **p, size_t n)
+{
+    HIPCHK(h, hipMalloc((void **)p, n * sizeof(T)));
+    return RPE_OK;
+}
+#define DM(h, p, n) do { int r_ = dmalloc(h, &(p), (size_t)(n)); if (r_) return r_; } while (0)
+
+static int build_tables(rpe_handle *h)
+{
+    const RpeDeviceLayout &L = h->lay;
+    // tiles
+    std::vector<RpeTile> full, fast;
+    for (int l = 0; l < RPE_NLEVELS; ++l) {
+        const RpeLevel &v = L.lv[l];
+        for (int y = 0; y < v.h; y += 16)
+            for (int x = 0; x < v.pitch; x += 64) full.push_back({(short)l, (short)x, (short)y, 0});
+        if (v.w > 2 * RPE_EDGE && v.h > 2 * RPE_EDGE)
+            for (int y = 28; y < v.h - 28; y += 16)
+                for (int x = 28; x < v.w - 28; x += 64) fast.push_back({(short)l, (short)x, (short)y, 0});
+    }
+    h->n_tiles_full = (int)full.size(); h->n_tiles_fast = (int)fast.size();
+    DM(h, h->d_tiles_full, full.size());
+    DM(h, h->d_tiles_fast, fast.size() ? fast.size() : 1);
+    HIPCHK(h, hipMemcpy(h->d_tiles_full, full.data(), full.size() * sizeof(RpeTile), hipMemcpyHostToDevice));
+    if (!fast.empty()) HIPCHK(h, hipMemcpy(h->d_tiles_fast, fast.data(), fast.size() * sizeof(RpeTile), hipMemcpyHostToDevice));
+    // resize coefficients
+    int ncoef = L.lv[RPE_NLEVELS - 1].coef_off + 2 * (L.lv[RPE_NLEVELS - 1].w + L.lv[RPE_NLEVELS - 1].h);
+    std::vector<int> coef((size_t)ncoef, 0);
+    for (int l = 1; l < RPE_NLEVELS; ++l) {
+        const RpeLevel &S = L.lv[l - 1], &D = L.lv[l];
+        int *xo = coef.data() + D.coef_off, *xa = xo + D.w, *yo = xa + D.w, *ya = yo + D.h;
+        lin_coeffs(S.w, D.w, xo, xa);
+        lin_coeffs(S.h, D.h, yo, ya);
+    }
+    DM(h, h->d_coef, ncoef);
+    HIPCHK(h, hipMemcpy(h->d_coef, coef.data(), sizeof(int) * (size_t)ncoef, hipMemcpyHostToDevice));
+    // intensity-centroid disc (orb.cpp umax table)
+    {
+        int umax[RPE_HALF_PATCH + 2];
+        int v, v0, vmax = (int)floor(RPE_HALF_PATCH * sqrt(2.f) / 2 + 1);
+        int vmin = (int)ceil(RPE_HALF_PATCH * sqrt(2.f) / 2);
+        for (v = 0; v <= vmax; ++v) umax[v] = cv_round(sqrt((double)RPE_HALF_PATCH * RPE_HALF_PATCH - v * v));
+        for (v = RPE_HALF_PATCH, v0 = 0; v >= vmin; --v) {
+            while (umax[v0] == umax[v0 + 1]) ++v0;
+            umax[v] = v0;
+            ++v0;
+        }
+        std::vector<signed char> disc;
+        for (int vv = -RPE_HALF_PATCH; vv <= RPE_HALF_PATCH; ++vv) {
+            int d = umax[abs(vv)];
+            for (int u = -d; u <= d; ++u) { disc.push_back((signed char)u); disc.push_back((signed char)vv); }
+        }
+        if (disc.size() / 2 > 768) { h->err = "disc table overflow"; return RPE_ERR_INVALID; }
+        rpe_orb_upload_disc(disc.data(), (int)(disc.size() / 2));
+    }
+    // RANSAC subset stream per M (ptsetreg.cpp getSubset; RNG seeded (uint64)-1 per run)
+    const int mm = h->cfg.max_matches, iters = h->cfg.ransac_max_iters;
+    {
+        std::vector<unsigned short> sub((size_t)(mm + 1) * iters * 5, 0);
+        for (int M = 6; M <= mm; ++M) {
+            uint64_t st = 0xFFFFFFFFFFFFFFFFULL;
+            unsigned short *s = sub.data() + (size_t)M * iters * 5;
+            for (int it = 0; it < iters; ++it, s += 5)
+                for (int i = 0; i < 5; ++i) {
+                    int v, dup;
+                    do {
+                        v = (int)(rng_next(st) % (uint32_t)M);
+                        dup = 0;
+                        for (int k = 0; k < i; ++k) if (s[k] == v) dup = 1;
+                    } while (dup);
+                    s[i] = (unsigned short)v;
+                }
+        }
+        DM(h, h->d_subsets, sub.size());
+        HIPCHK(h, hipMemcpy(h->d_subsets, sub.data(), sub.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    }
+    // RANSACUpdateNumIters(p, ep, 5, niters) terms per (M, goodCount)
+    {
+        size_t n = (size_t)(mm + 1) * (mm + 2) / 2;
+        std::vector<double> den(n, 0.); std::vector<int> rnd(n, 0);
+        double p = h->cfg.ransac_prob;
+        p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
+        double num0 = (1. - p) > DBL_MIN ? (1. - p) : DBL_MIN;
+        h->nit_num = log(num0);
+        for (int M = 1; M <= mm; ++M)
+            for (int g = 0; g <= M; ++g) {
+                size_t idx = (size_t)M * (M + 1) / 2 + g;
+                double ep = (double)(M - g) / M;
+                ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
+                double denom = 1. - pow(1. - ep, 5);
+                if (denom < DBL_MIN) { den[idx] = 0.; rnd[idx] = -1; continue; }
+                denom = log(denom);
+                den[idx] = denom;
+                rnd[idx] = denom >= 0 ? 0 : cv_round(h->nit_num / denom);
+            }
+        DM(h, h->d_nit_denom, n); DM(h, h->d_nit_round, n);
+        HIPCHK(h, hipMemcpy(h->d_nit_denom, den.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->d_nit_round, rnd.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    }
+    return RPE_OK;
+}
+
+static int alloc_workspace(rpe_handle *h)
+{
+    const RpeDeviceLayout &L = h->lay;
+    const size_t NI = (size_t)h->n_img_cap, B = (size_t)h->cfg.max_batch, mm = (size_t)h->cfg.max_matches;
+    DM(h, h->d_pyr, NI * L.stride); DM(h, h->d_bufA, NI * L.stride); DM(h, h->d_bufB, NI * L.stride);
+    HIPCHK(h, hipMemset(h->d_bufA, 0, NI * L.stride));
+    HIPCHK(h, hipMemset(h->d_bufB, 0, NI * L.stride));
+    HIPCHK(h, hipMemset(h->d_pyr, 0, NI * L.stride));
+    const size_t img = (size_t)h->cfg.width * h->cfg.height;
+    DM(h, h->d_stage1, B * img); DM(h, h->d_stage2, B * img);
+    DM(h, h->d_hist, NI * RPE_NLEVELS * 256);
+    DM(h, h->d_cand_xy, NI * L.cand_total); DM(h, h->d_cand_resp, NI * L.cand_total);
+    DM(h, h->d_cand_count, NI * RPE_NLEVELS);
+    DM(h, h->d_kp_xy, NI * L.kcap); DM(h, h->d_kp_resp, NI * L.kcap); DM(h, h->d_kp_angle, NI * L.kcap);
+    DM(h, h->d_kp_pt, NI * L.kcap); DM(h, h->d_kp_count, NI);
+    DM(h, h->d_desc, NI * L.kcap * 32);
+    HIPCHK(h, hipMemset(h->d_kp_pt, 0, NI * L.kcap * sizeof(float2)));
+    HIPCHK(h, hipMemset(h->d_kp_count, 0, NI * sizeof(int)));
+    DM(h, h->d_m_q, B * mm); DM(h, h->d_m_t, B * mm); DM(h, h->d_m_d, B * mm); DM(h, h->d_m_n, B);
+    DM(h, h->d_pts1, B * mm); DM(h, h->d_pts2, B * mm);
+    DM(h, h->d_n1, B * mm); DM(h, h->d_n2, B * mm);
+    DM(h, h->d_rstate, B); DM(h, h->d_found, B);
+    DM(h, h->d_models, B * RPE_RANSAC_CHUNK * RPE_MAX_MODELS * 9);
+    DM(h, h->d_nmodels, B * RPE_RANSAC_CHUNK);
+    DM(h, h->d_mask, B * mm);
+    DM(h, h->d_R, B * 9); DM(h, h->d_t, B * 3); DM(h, h->d_E, B * 9);
+    DM(h, h->d_inliers, B); DM(h, h->d_status, B);
+    DM(h, h->d_K, 9);
+    return RPE_OK;
+}
+
+extern "C" int rpe_create(const rpe_config *cfg, rpe_handle **out)
+{
+    if (!cfg || !out) { g_create_err = "null argument"; return RPE_ERR_INVALID; }
+    *out = nullptr;
+    if (cfg->abi_version != RPE_ABI_VERSION) { g_create_err = "ABI version mismatch"; return RPE_ERR_INVALID; }
+    if (cfg->feature_method != RPE_FEATURE_ORB || cfg->norm_type != RPE_NORM_HAMMING) {
+        g_create_err = "only ORB + Hamming is implemented on the HIP path"; return RPE_ERR_INVALID;
+    }
+    if (cfg->width < 96 || cfg->height < 96 || cfg->width > 4095 || cfg->height > 4095 || cfg->max_batch < 1 ||
+        cfg->nfeatures < 1 || cfg->nfeatures > 8000 || cfg->max_matches < 5 || cfg->max_matches > 2048 ||
+        cfg->ransac_max_iters < 1 || cfg->ransac_max_iters > 4096 || cfg->fast_threshold < 1 || cfg->fast_threshold > 254) {
+        g_create_err = "configuration out of supported range"; return RPE_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_err = "no HIP device available: the MI355X path has no CPU fallback"; return RPE_ERR_HIP;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_err = "bad device ordinal"; return RPE_ERR_INVALID; }
+    rpe_handle *h = new rpe_handle();
+    h->cfg = *cfg;
+    h->n_img_cap = 2 * cfg->max_batch;
+    int rc = RPE_OK;
+    do {
+        if (hipSetDevice(cfg->device) != hipSuccess) { h->err = "hipSetDevice failed"; rc = RPE_ERR_HIP; break; }
+        if (hipStreamCreate(&h->stream) != hipSuccess) { h->err = "hipStreamCreate failed"; rc = RPE_ERR_HIP; break; }
+        build_layout(h);
+        if ((rc = build_tables(h)) != RPE_OK) break;
+        if ((rc = alloc_workspace(h)) != RPE_OK) break;
+        for (int i = 0; i <= RPE_STAGE_COUNT; ++i)
+            if (hipEventCreate(&h->ev[i]) != hipSuccess) { h->err = "hipEventCreate failed"; rc = RPE_ERR_HIP; break; }
+    } while (0);
+    if (rc != RPE_OK) { g_create_err = h->err; rpe_destroy(h); return rc; }
+    *out = h;
+    return RPE_OK;
+}
+
+extern "C" void rpe_destroy(rpe_handle *h)
+{
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    void *ptrs[] = {h->d_tiles_full, h->d_tiles_fast, h->d_coef, h->d_pyr, h->d_bufA, h->d_bufB, h->d_stage1, h->d_stage2,
+                    h->d_hist, h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_angle,
+                    h->d_kp_pt, h->d_kp_count, h->d_desc, h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2,
+                    h->d_subsets, h->d_nit_denom, h->d_nit_round, h->d_rstate, h->d_n1, h->d_n2, h->d_found, h->d_models,
+                    h->d_nmodels, h->d_mask, h->d_R, h->d_t, h->d_E, h->d_inliers, h->d_status, h->d_K};
+    for (void *p : ptrs) if (p) hipFree(p);
+    for (void *p : h->user_allocs) hipFree(p);
+    for (int i = 0; i <= RPE_STAGE_COUNT; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+// ------------------------------------------------------------ device buffers
+extern "C" int rpe_device_malloc(rpe_handle *h, size_t bytes, void **d_ptr)
+{
+    if (!h || !d_ptr) return RPE_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMalloc(d_ptr, bytes));
+    h->user_allocs.push_back(*d_ptr);
+    return RPE_OK;
+}
+extern "C" int rpe_device_free(rpe_handle *h, void *d_ptr)
+{
+    if (!h) return RPE_ERR_INVALID;
+    for (size_t i = 0; i < h->user_allocs.size(); ++i)
+        if (h->user_allocs[i] == d_ptr) { h->user_allocs.erase(h->user_allocs.begin() + i); HIPCHK(h, hipFree(d_ptr)); return RPE_OK; }
+    h->err = "rpe_device_free: unknown pointer";
+    return RPE_ERR_INVALID;
+}
+extern "C" int rpe_memcpy_h2d(rpe_handle *h, void *d, const void *s, size_t n)
+{
+    if (!h) return RPE_ERR_INVALID;
+    HIPCHK(h, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RPE_OK;
+}
+extern "C" int rpe_memcpy_d2h(rpe_handle *h, void *d, const void *s, size_t n)
+{
+    if (!h) return RPE_ERR_INVALID;
+    HIPCHK(h, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RPE_OK;
+}
+extern "C" int rpe_synchronize(rpe_handle *h)
+{
+    if (!h) return RPE_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RPE_OK;
+}
+
+// ------------------------------------------------------------- orchestration
+#define MARK(h, stage) do { if ((h)->profiling) hipEventRecord((h)->ev[stage], (h)->stream); } while (0)
+
+// copies level 0 of every image into the pyramid buffer (device to device)
+static int load_level0(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, int nb)
+{
+    const int W = h->cfg.width, H = h->cfg.height;
+    const RpeLevel &v = h->lay.lv[0];
+    for (int i = 0; i < na + nb; ++i) {
+        const uint8_t *src = i < na ? d_a + (size_t)i * W * H : d_b + (size_t)(i - na) * W * H;
+        uint8_t *dst = h->d_pyr + (size_t)i * h->lay.stride + v.off;
+        HIPCHK(h, hipMemcpy2DAsync(dst, v.pitch, src, W, W, H, hipMemcpyDeviceToDevice, h->stream));
+    }
+    return RPE_OK;
+}
+
+// strided batch copy kernel-free variant: when pitch == W one 2-D copy moves all images
+static int load_level0_fast(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, int nb)
+{
+    const int W = h->cfg.width, H = h->cfg.height;
+    const RpeLevel &v = h->lay.lv[0];
+    if (v.pitch != W) return load_level0(h, d_a, d_b, na, nb);
+    const size_t img = (size_t)W * H;
+    if (na) HIPCHK(h, hipMemcpy2DAsync(h->d_pyr + v.off, h->lay.stride, d_a, img, img, na, hipMemcpyDeviceToDevice, h->stream));
+    if (nb) HIPCHK(h, hipMemcpy2DAsync(h->d_pyr + (size_t)na * h->lay.stride + v.off, h->lay.stride, d_b, img, img, nb,
+                                       hipMemcpyDeviceToDevice, h->stream));
+    return RPE_OK;
+}
+
+static int run_orb(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, int nb)
+{
+    const int n = na + nb;
+    MARK(h, RPE_STAGE_PYRAMID);
+    int rc = load_level0_fast(h, d_a, d_b, na, nb);
+    if (rc) return rc;
+    rpe_launch_pyramid(h, n);
+    MARK(h, RPE_STAGE_FAST);      rpe_launch_fast(h, n);
+    MARK(h, RPE_STAGE_NMS);       rpe_launch_nms(h, n);
+    MARK(h, RPE_STAGE_SELECT);    rpe_launch_select(h, n);
+    MARK(h, RPE_STAGE_HARRIS);    rpe_launch_harris(h, n);
+    MARK(h, RPE_STAGE_KEYPOINTS); rpe_launch_keypoints(h, n);
+    MARK(h, RPE_STAGE_ANGLE);     rpe_launch_angle(h, n);
+    MARK(h, RPE_STAGE_BLUR);      rpe_launch_blur(h, n);
+    MARK(h, RPE_STAGE_DESCRIBE);  rpe_launch_describe(h, n);
+    MARK(h, RPE_STAGE_MATCH);
+    HIPCHK(h, hipGetLastError());
+    return RPE_OK;
+}
+
+static int set_K(rpe_handle *h, const double K[9])
+{
+    HIPCHK(h, hipMemcpyAsync(h->d_K, K, sizeof(double) * 9, hipMemcpyHostToDevice, h->stream));
+    return RPE_OK;
+}
+
+extern "C" int rpe_enqueue_batch_device(rpe_handle *h, const uint8_t *d_imgs1, const uint8_t *d_imgs2, int B, const double K[9])
+{
+    if (!h || !d_imgs1 || !d_imgs2 || !K || B < 1) return RPE_ERR_INVALID;
+    if (B > h->cfg.max_batch) { h->err = "batch exceeds max_batch"; return RPE_ERR_CAPACITY; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = set_K(h, K);
+    if (rc) return rc;
+    if ((rc = run_orb(h, d_imgs1, d_imgs2, B, B)) != RPE_OK) return rc;
+    rpe_launch_match(h, B);
+    MARK(h, RPE_STAGE_RANSAC);
+    rpe_launch_ransac(h, B, false);
+    MARK(h, RPE_STAGE_POSE);
+    rpe_launch_pose(h, B, true);
+    if (h->profiling) { hipEventRecord(h->ev[RPE_STAGE_COUNT], h->stream); h->ev_valid = true; }
+    HIPCHK(h, hipGetLastError());
+    return RPE_OK;
+}
+
+extern "C" int rpe_fetch_results(rpe_handle *h, int B, double *R, double *t, int32_t *inliers, int32_t *n_matches, int32_t *status)
+{
+    if (!h || B < 1 || B > h->cfg.max_batch) return RPE_ERR_INVALID;
+    if (R) HIPCHK(h, hipMemcpyAsync(R, h->d_R, sizeof(double) * 9 * B, hipMemcpyDeviceToHost, h->stream));
+    if (t) HIPCHK(h, hipMemcpyAsync(t, h->d_t, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, h->stream));
+    if (inliers) HIPCHK(h, hipMemcpyAsync(inliers, h->d_inliers, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
+    if (n_matches) HIPCHK(h, hipMemcpyAsync(n_matches, h->d_m_n, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
+    if (status) HIPCHK(h, hipMemcpyAsync(status, h->d_status, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RPE_OK;
+}
+
+extern "C" int rpe_estimate_batch_device(rpe_handle *h, const uint8_t *d_imgs1, const uint8_t *d_imgs2, int B, const double K[9],
+                                         double *R, double *t, int32_t *inliers, int32_t *n_matches, int32_t *status)
+{
+    int rc = rpe_enqueue_batch_device(h, d_imgs1, d_imgs2, B, K);
+    if (rc) return rc;
+    return rpe_fetch_results(h, B, R, t, inliers, n_matches, status);
+}
+
+extern "C" int rpe_estimate_batch(rpe_handle *h, const uint8_t *h_imgs1, const uint8_t *h_imgs2, int B, const double K[9],
+                                  double *R, double *t, int32_t *inliers, int32_t *n_matches, int32_t *status)
+{
+    if (!h || !h_imgs1 || !h_imgs2 || B < 1) return RPE_ERR_INVALID;
+    if (B > h->cfg.max_batch) { h->err = "batch exceeds max_batch"; return RPE_ERR_CAPACITY; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t img = (size_t)h->cfg.width * h->cfg.height;
+    HIPCHK(h, hipMemcpyAsync(h->d_stage1, h_imgs1, img * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_stage2, h_imgs2, img * B, hipMemcpyHostToDevice, h->stream));
+    return rpe_estimate_batch_device(h, h->d_stage1, h->d_stage2, B, K, R, t, inliers, n_matches, status);
+}
+
+extern "C" int rpe_fetch_matched_points(rpe_handle *h, int B, float *pts1, float *pts2)
+{
+    if (!h || B < 1 || B > h->cfg.max_batch) return RPE_ERR_INVALID;
+    const size_t n = sizeof(float2) * (size_t)B * h->cfg.max_matches;
+    if (pts1) HIPCHK(h, hipMemcpyAsync(pts1, h->d_pts1, n, hipMemcpyDeviceToHost, h->stream));
+    if (pts2) HIPCHK(h, hipMemcpyAsync(pts2, h->d_pts2, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RPE_OK;
+}
+
+// ---------------------------------------------------------------- stage API
+extern "C" int rpe_orb_detect_and_compute(rpe_handle *h, const uint8_t *h_imgs, int n_images,
+                                          rpe_keypoint *kps, uint8_t *desc, int32_t *counts)
+{
+    if (!h || !h_imgs || n_images < 1) return RPE_ERR_INVALID;
+    if (n_images > h->n_img_cap) { h->err = "n_images exceeds 2*max_batch"; return RPE_ERR_CAPACITY; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t img = (size_t)h->cfg.width * h->cfg.height;
+    const int na = n_images < h->cfg.max_batch ? n_images : h->cfg.max_batch, nb = n_images - na;
+    HIPCHK(h, hipMemcpyAsync(h->d_stage1, h_imgs, img * na, hipMemcpyHostToDevice, h->stream));
+    if (nb) HIPCHK(h, hipMemcpyAsync(h->d_stage2, h_imgs + img * na, img * nb, hipMemcpyHostToDevice, h->stream));
+    int rc = run_orb(h, h->d_stage1, h->d_stage2, na, nb);
+    if (rc) return rc;
+    const int kcap = h->lay.kcap;
+    std::vector<unsigned> xy((size_t)n_images * kcap);
+    std::vector<float> resp((size_t)n_images * kcap), ang((size_t)n_images * kcap);
+    std::vector<float2> pt((size_t)n_images * kcap);
+    std::vector<int> cnt(n_images);
+    HIPCHK(h, hipMemcpyAsync(xy.data(), h->d_kp_xy, xy.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(resp.data(), h->d_kp_resp, resp.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(ang.data(), h->d_kp_angle, ang.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(pt.data(), h->d_kp_pt, pt.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(cnt.data(), h->d_kp_count, cnt.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    if (desc) HIPCHK(h, hipMemcpyAsync(desc, h->d_desc, (size_t)n_images * kcap * 32, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n_images; ++i) {
+        if (counts) counts[i] = cnt[i];
+        if (!kps) continue;
+        for (int k = 0; k < cnt[i]; ++k) {
+            size_t g = (size_t)i * kcap + k;
+            rpe_keypoint &o = kps[g];
+            o.x = pt[g].x; o.y = pt[g].y; o.angle = ang[g]; o.response = resp[g];
+            o.octave = (int)(xy[g] >> 24); o.lx = (int)(xy[g] & 0xFFF); o.ly = (int)((xy[g] >> 12) & 0xFFF);
+        }
+    }
+    return RPE_OK;
+}
+
+extern "C" int64_t rpe_orb_pyramid_pixels(const rpe_handle *h)
+{
+    if (!h) return 0;
+    int64_t n = 0;
+    for (int l = 0; l < RPE_NLEVELS; ++l) n += (int64_t)h->lay.lv[l].w * h->lay.lv[l].h;
+    return n;
+}
+
+extern "C" int rpe_orb_debug_fetch(rpe_handle *h, int index, int which, uint8_t *h_out)
+{
+    if (!h || !h_out || index < 0 || index >= h->n_img_cap) return RPE_ERR_INVALID;
+    const uint8_t *src = which == 0 ? h->d_pyr : (which == 2 ? h->d_bufB : h->d_bufA);
+    std::vector<uint8_t> tmp((size_t)h->lay.stride);
+    HIPCHK(h, hipMemcpyAsync(tmp.data(), src + (size_t)index * h->lay.stride, tmp.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    uint8_t *o = h_out;
+    for (int l = 0; l < RPE_NLEVELS; ++l) {
+        const RpeLevel &v = h->lay.lv[l];
+        for (int y = 0; y < v.h; ++y, o += v.w) memcpy(o, tmp.data() + v.off + (size_t)y * v.pitch, v.w);
+    }
+    return RPE_OK;
+}
+
+extern "C" int rpe_match_hamming(rpe_handle *h, const uint8_t *h_desc1, const int32_t *n1, const uint8_t *h_desc2,
+                                 const int32_t *n2, int B, int32_t *qidx, int32_t *tidx, int32_t *dist, int32_t *n_matches)
+{
+    if (!h || !h_desc1 || !h_desc2 || !n1 || !n2 || B < 1) return RPE_ERR_INVALID;
+    if (B > h->cfg.max_batch) { h->err = "batch exceeds max_batch"; return RPE_ERR_CAPACITY; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t per = (size_t)h->lay.kcap * 32, mm = h->cfg.max_matches;
+    for (int i = 0; i < B; ++i) if (n1[i] < 0 || n2[i] < 0 || n1[i] > h->lay.kcap || n2[i] > h->lay.kcap) {
+        h->err = "descriptor count exceeds keypoint capacity"; return RPE_ERR_INVALID;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_desc, h_desc1, per * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_desc + per * B, h_desc2, per * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_kp_count, n1, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_kp_count + B, n2, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+    rpe_launch_match(h, B);
+    HIPCHK(h, hipGetLastError());
+    if (qidx) HIPCHK(h, hipMemcpyAsync(qidx, h->d_m_q, sizeof(int) * mm * B, hipMemcpyDeviceToHost, h->stream));
+    if (tidx) HIPCHK(h, hipMemcpyAsync(tidx, h->d_m_t, sizeof(int) * mm * B, hipMemcpyDeviceToHost, h->stream));
+    if (dist) HIPCHK(h, hipMemcpyAsync(dist, h->d_m_d, sizeof(int) * mm * B, hipMemcpyDeviceToHost, h->stream));
+    if (n_matches) HIPCHK(h, hipMemcpyAsync(n_matches, h->d_m_n, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RPE_OK;
+}
+
+static int upload_points(rpe_handle *h, const float *p1, const float *p2, const int32_t *m, int B)
+{
+    const size_t mm = h->cfg.max_matches;
+    for (int i = 0; i < B; ++i) if (m[i] < 0 || m[i] > (int)mm) { h->err = "match count exceeds max_matches"; return RPE_ERR_INVALID; }
+    HIPCHK(h, hipMemcpyAsync(h->d_pts1, p1, sizeof(float2) * mm * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_pts2, p2, sizeof(float2) * mm * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_m_n, m, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+    return RPE_OK;
+}
+
+extern "C" int rpe_find_essential(rpe_handle *h, const float *h_pts1, const float *h_pts2, const int32_t *m, int B,
+                                  const double K[9], double *E, uint8_t *mask, int32_t *found, int32_t *info)
+{
+    if (!h || !h_pts1 || !h_pts2 || !m || !K || B < 1) return RPE_ERR_INVALID;
+    if (B > h->cfg.max_batch) { h->err = "batch exceeds max_batch"; return RPE_ERR_CAPACITY; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = upload_points(h, h_pts1, h_pts2, m, B);
+    if (rc) return rc;
+    if ((rc = set_K(h, K)) != RPE_OK) return rc;
+    HIPCHK(h, hipMemsetAsync(h->d_E, 0, sizeof(double) * 9 * B, h->stream));
+    rpe_launch_ransac(h, B, true);
+    HIPCHK(h, hipGetLastError());
+    std::vector<RpeRansacState> st(B);
+    HIPCHK(h, hipMemcpyAsync(st.data(), h->d_rstate, sizeof(RpeRansacState) * B, hipMemcpyDeviceToHost, h->stream));
+    if (mask) HIPCHK(h, hipMemcpyAsync(mask, h->d_mask, (size_t)h->cfg.max_matches * B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < B; ++i) {
+        if (E) memcpy(E + 9 * i, st[i].E, sizeof(double) * 9);
+        if (found) found[i] = st[i].found;
+        if (info) { info[4 * i] = st[i].best_count; info[4 * i + 1] = st[i].best_iter; info[4 * i + 2] = st[i].best_model; info[4 * i + 3] = st[i].iters_run; }
+    }
+    return RPE_OK;
+}
+
+extern "C" int rpe_recover_pose(rpe_handle *h, const double *h_E, const float *h_pts1, const float *h_pts2, const int32_t *m,
+                                int B, const double K[9], double *R, double *t, int32_t *inliers)
+{
+    if (!h || !h_E || !h_pts1 || !h_pts2 || !m || !K || B < 1) return RPE_ERR_INVALID;
+    if (B > h->cfg.max_batch) { h->err = "batch exceeds max_batch"; return RPE_ERR_CAPACITY; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = upload_points(h, h_pts1, h_pts2, m, B);
+    if (rc) return rc;
+    if ((rc = set_K(h, K)) != RPE_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_E, h_E, sizeof(double) * 9 * B, hipMemcpyHostToDevice, h->stream));
+    rpe_launch_pose(h, B, false);
+    HIPCHK(h, hipGetLastError());
+    return rpe_fetch_results(h, B, R, t, inliers, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------- profiling
+static const char *kStageNames[RPE_STAGE_COUNT] = {"pyramid", "fast", "nms", "select", "harris", "keypoints",
+                                                   "angle", "blur", "describe", "match", "ransac", "pose"};
+extern "C" const char *rpe_stage_name(int s) { return (s >= 0 && s < RPE_STAGE_COUNT) ? kStageNames[s] : "?"; }
+extern "C" int rpe_set_profiling(rpe_handle *h, int enable)
+{
+    if (!h) return RPE_ERR_INVALID;
+    h->profiling = enable != 0; h->ev_valid = false;
+    return RPE_OK;
+}
+extern "C" int rpe_get_stage_ms(rpe_handle *h, float *ms)
+{
+    if (!h || !ms) return RPE_ERR_INVALID;
+    if (!h->ev_valid) { h->err = "no profiled batch recorded"; return RPE_ERR_INVALID; }
+    HIPCHK(h, hipEventSynchronize(h->ev[RPE_STAGE_COUNT]));
+    for (int i = 0; i < RPE_STAGE_COUNT; ++i) HIPCHK(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    return RPE_OK;
+}

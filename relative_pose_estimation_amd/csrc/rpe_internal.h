@@ -1,0 +1,116 @@
+// rpe_internal.h -- shared declarations of the MI355X (gfx950) relative-pose engine.
+// Host handle, HBM workspace layout and kernel-launcher prototypes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/rpe_amd.h"
+
+#define RPE_NLEVELS RPE_ORB_LEVELS
+#define RPE_EDGE 31            // ORB edgeThreshold (cv2 default; pose_estimator.py:85-91 leaves it)
+#define RPE_HALF_PATCH 15      // patchSize 31
+#define RPE_RANSAC_CHUNK 64    // RANSAC iterations evaluated per launch group
+#define RPE_MAX_MODELS 10
+
+// ---- HBM layout of one image's pyramid-shaped buffers ---------------------
+// Level l is stored with row pitch align16(w_l) at byte offset off[l] (256-B
+// aligned); images are `stride` bytes apart.  The raw pyramid, the FAST score /
+// blurred pyramid buffer and the NMS buffer all use this layout.
+struct RpeLevel {
+    int w, h, pitch;
+    int quota;        // features kept on this level (orb.cpp nfeaturesPerLevel)
+    int ccap;         // candidate capacity 4*quota+256
+    int cand_off;     // offset of this level inside per-image candidate arrays
+    float scale;      // (float)pow(1.1f, l)
+    long long off;    // byte offset inside the per-image pyramid buffer
+    int coef_off;     // offset of xo/xa (w entries) then yo/ya (h entries) in coef table
+};
+
+struct RpeDeviceLayout {       // passed by value to kernels
+    RpeLevel lv[RPE_NLEVELS];
+    long long stride;          // bytes per image in pyramid-shaped buffers
+    int cand_total;            // candidates capacity per image (sum ccap)
+    int kcap;                  // keypoints capacity per image
+    int fast_thr;
+};
+
+struct RpeTile { short level, tx, ty, pad; };
+
+// per-pair RANSAC state in HBM
+struct RpeRansacState {
+    int best_count;   // maxGoodCount
+    int best_iter;
+    int best_model;
+    int niters;       // current loop bound
+    int next_iter;    // first iteration of the next chunk
+    int done;
+    int found;
+    int M;
+    int iters_run;    // loop trip count so far (ptsetreg.cpp `iter` at exit)
+    int pad_;
+    double E[9];      // best model so far
+};
+
+struct rpe_handle {
+    rpe_config cfg;
+    std::string err;
+    hipStream_t stream = nullptr;
+    RpeDeviceLayout lay;
+    int n_img_cap = 0;              // 2*max_batch
+    // tile tables
+    RpeTile *d_tiles_full = nullptr;  int n_tiles_full = 0;   // 64x16 tiles covering every level
+    RpeTile *d_tiles_fast = nullptr;  int n_tiles_fast = 0;   // tiles covering [28,w-28)x[28,h-28)
+    int *d_coef = nullptr;            // resize coefficient tables
+    // image-shaped buffers
+    uint8_t *d_pyr = nullptr, *d_bufA = nullptr, *d_bufB = nullptr;
+    uint8_t *d_stage1 = nullptr, *d_stage2 = nullptr; // staging for host-image API
+    // detection
+    unsigned *d_hist = nullptr;       // [img][level][256]
+    unsigned *d_cand_xy = nullptr;    // [img][cand_total]  y<<16|x
+    float *d_cand_resp = nullptr;     // [img][cand_total]
+    int *d_cand_count = nullptr;      // [img][level]
+    unsigned *d_kp_xy = nullptr;      // [img][kcap]  x | y<<12 | level<<24
+    float *d_kp_resp = nullptr, *d_kp_angle = nullptr;
+    float2 *d_kp_pt = nullptr;
+    int *d_kp_count = nullptr;        // [img]
+    uint8_t *d_desc = nullptr;        // [img][kcap][32]
+    // matching
+    int *d_m_q = nullptr, *d_m_t = nullptr, *d_m_d = nullptr, *d_m_n = nullptr;
+    float2 *d_pts1 = nullptr, *d_pts2 = nullptr;   // [pair][max_matches]
+    // RANSAC
+    unsigned short *d_subsets = nullptr;  // [M 0..max_matches][iters][5]
+    double *d_nit_denom = nullptr;        // [(M,g)] log(1-(1-ep)^5) or NaN-coded flags
+    int *d_nit_round = nullptr;           // [(M,g)] cvRound(num/denom), -1 => denom<DBL_MIN (return 0)
+    double nit_num = 0;                   // log(1-p)
+    RpeRansacState *d_rstate = nullptr;
+    double2 *d_n1 = nullptr, *d_n2 = nullptr;   // K-normalised matched points [pair][max_matches]
+    int *d_found = nullptr;                   // [pair]
+    double *d_models = nullptr;           // [pair][CHUNK][10][9]
+    int *d_nmodels = nullptr;             // [pair][CHUNK]
+    uint8_t *d_mask = nullptr;            // [pair][max_matches]
+    // results
+    double *d_R = nullptr, *d_t = nullptr, *d_E = nullptr;
+    int *d_inliers = nullptr, *d_status = nullptr;
+    double *d_K = nullptr;
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[RPE_STAGE_COUNT + 1] = {};
+    float stage_ms[RPE_STAGE_COUNT] = {};
+    bool ev_valid = false;
+    std::vector<void *> user_allocs;
+};
+
+// ---- kernel launchers (defined in the .hip files) --------------------------
+void rpe_launch_pyramid(rpe_handle *h, int n_img);
+void rpe_launch_fast(rpe_handle *h, int n_img);
+void rpe_launch_nms(rpe_handle *h, int n_img);
+void rpe_launch_select(rpe_handle *h, int n_img);
+void rpe_launch_harris(rpe_handle *h, int n_img);
+void rpe_launch_keypoints(rpe_handle *h, int n_img);
+void rpe_launch_angle(rpe_handle *h, int n_img);
+void rpe_launch_blur(rpe_handle *h, int n_img);
+void rpe_launch_describe(rpe_handle *h, int n_img);
+void rpe_launch_match(rpe_handle *h, int B);
+void rpe_launch_ransac(rpe_handle *h, int B, bool want_mask);
+void rpe_launch_pose(rpe_handle *h, int B, bool set_status);

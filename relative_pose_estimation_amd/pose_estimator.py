@@ -1,0 +1,145 @@
+"""Drop-in PoseEstimator backed by librpe_amd.so (HIP kernels on MI355X).
+
+Mirrors reference src/core/pose_estimator.py: same constructor signature and
+defaults (:19-32), estimate(img1, img2, R_prev=None) -> (R, t) (:487-569),
+estimate_with_debug(...) -> dict with the reference's keys (:571-688, dict
+:624-633), same exception types and messages (:96, :129, :508-509, :514-515,
+:529-530).  Added: estimate_batch() for many pairs per call.
+
+Scope: the feature -> match -> essential -> pose path.  VP refinement
+(:160-481, :536-567) is outside the accelerated path: the
+kwargs are accepted and stored; requesting it has no effect on R here and
+'vp_used' is always False.
+"""
+import numpy as np
+
+from . import _capi
+
+
+class PoseEstimator:
+    def __init__(self,
+                 camera_matrix,
+                 feature_method="ORB",
+                 norm_type="Hamming",
+                 max_matches=500,
+                 nfeatures=4000,
+                 use_vp_refinement=False,
+                 vp_max_lines=120,
+                 vp_max_pairs=3000,
+                 vp_acc_min=8e5,
+                 vp_vp2_min=8000.0,
+                 vp_iters=12,
+                 vp_lm_lambda=1e-2,
+                 vp_cost_improve_eps=1e-3,
+                 device=0,
+                 max_batch=1):
+        self.K = np.asarray(camera_matrix, dtype=np.float64)
+        self.feature_method = feature_method
+        self.norm_type = norm_type
+        self.max_matches = max_matches
+        self.nfeatures = nfeatures
+        self.use_vp_refinement = use_vp_refinement
+        self.vp_max_lines = vp_max_lines
+        self.vp_max_pairs = vp_max_pairs
+        self.vp_acc_min = vp_acc_min
+        self.vp_vp2_min = vp_vp2_min
+        self.vp_iters = vp_iters
+        self.vp_lm_lambda = vp_lm_lambda
+        self.vp_cost_improve_eps = vp_cost_improve_eps
+        self.device = device
+        self.max_batch = max_batch
+        # same validation order and messages as _create_feature_extractor / _create_matcher
+        method = self.feature_method.upper()
+        if method == "ORB":
+            self._feature = _capi.FEATURE_ORB
+        elif method == "SIFT":
+            self._feature = _capi.FEATURE_SIFT
+        else:
+            raise ValueError(f"Unknown feature extraction method: {method}")
+        norm = self.norm_type.upper()
+        if norm == "HAMMING":
+            self._norm = _capi.NORM_HAMMING
+        elif norm == "L2":
+            self._norm = _capi.NORM_L2
+        else:
+            raise ValueError(f"Unknown norm type: {norm}")
+        if self._feature != _capi.FEATURE_ORB or self._norm != _capi.NORM_HAMMING:
+            raise NotImplementedError("the MI355X path implements ORB + Hamming (SIFT + L2 is a later scope row)")
+        self._engines = {}
+
+    def _engine(self, height, width, batch):
+        key = (height, width)
+        eng = self._engines.get(key)
+        if eng is None or eng.max_batch < batch:
+            if eng is not None:
+                eng.close()
+            mm = self.max_matches if self.max_matches is not None else self.nfeatures + 64
+            eng = _capi.Engine(width, height, max_batch=max(batch, self.max_batch), nfeatures=self.nfeatures,
+                               max_matches=mm, device=self.device, feature_method=self._feature, norm_type=self._norm)
+            self._engines[key] = eng
+        return eng
+
+    @staticmethod
+    def _raise_for(status, n_matches):
+        if status == _capi.PAIR_NO_DESCRIPTORS:
+            raise RuntimeError("Could not compute descriptors for one of the images.")
+        if status == _capi.PAIR_INSUFFICIENT_MATCHES:
+            raise RuntimeError(f"Insufficient matches: {n_matches} (minimum 5 required)")
+        if status == _capi.PAIR_NO_ESSENTIAL:
+            raise RuntimeError("Could not estimate Essential matrix.")
+
+    @staticmethod
+    def _gray(img):
+        img = np.asarray(img)
+        if img.ndim != 2 or img.dtype != np.uint8:
+            raise ValueError("expected a 2-D uint8 grayscale image")
+        return img
+
+    def estimate_batch(self, imgs1, imgs2):
+        """(R[B,3,3], t[B,3,1], inliers[B], status[B]); a failing pair never aborts the batch."""
+        imgs1 = np.ascontiguousarray(imgs1, np.uint8); imgs2 = np.ascontiguousarray(imgs2, np.uint8)
+        B, H, W = imgs1.shape
+        eng = self._engine(H, W, B)
+        R, t, inl, nm, st = eng.estimate_batch(imgs1, imgs2, self.K)
+        self._last_n_matches = nm
+        return R, t, inl, st
+
+    def estimate(self, img1, img2, R_prev=None):
+        img1 = self._gray(img1); img2 = self._gray(img2)
+        eng = self._engine(img1.shape[0], img1.shape[1], 1)
+        R, t, inl, nm, st = eng.estimate_batch(img1[None], img2[None], self.K)
+        self._raise_for(int(st[0]), int(nm[0]))
+        return R[0], t[0]
+
+    def estimate_with_debug(self, img1, img2, R_prev=None):
+        img1 = self._gray(img1); img2 = self._gray(img2)
+        eng = self._engine(img1.shape[0], img1.shape[1], 1)
+        R, t, inl, nm, st = eng.estimate_batch(img1[None], img2[None], self.K)
+        self._raise_for(int(st[0]), int(nm[0]))
+        p1, p2 = eng.fetch_matched_points(1)
+        n = int(nm[0])
+        return {
+            'R': R[0],
+            't': t[0],
+            'num_matches': n,
+            'pts1': p1[0, :n].copy(),
+            'pts2': p2[0, :n].copy(),
+            'inliers': int(inl[0]),
+            'vp_used': False,
+            'vp_debug': {},
+        }
+
+    def close(self):
+        for e in self._engines.values():
+            e.close()
+        self._engines = {}
+
+
+def estimate_relative_pose(img1, img2, K, **kwargs):
+    """north_star's call surface: (R, t, inliers) for one image pair."""
+    est = PoseEstimator(K, **kwargs)
+    try:
+        d = est.estimate_with_debug(img1, img2)
+    finally:
+        est.close()
+    return d['R'], d['t'], d['inliers']

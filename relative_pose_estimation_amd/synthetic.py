@@ -1,0 +1,104 @@
+"""Seeded synthetic stereo pairs with known relative pose (own code).
+
+Scene (camera-1 frame): three fronto-parallel textured planes at depths 4, 7, 12.
+The two near planes exist only on a pseudo-random set of tiles, the far plane
+everywhere, so every pixel sees real parallax and occlusion.  Texture is a
+procedural multi-octave random-cell mosaic (cells of roughly 4..32 px), which
+gives FAST corners on all 12 ORB pyramid levels.  Both views are ray-cast from
+the same procedural scene (no image warping), then lightly blurred and noised.
+
+Pose convention = cv2.recoverPose / the reference: X2 = R @ X1 + t, |t| = 1.
+"""
+import numpy as np
+
+DEPTHS = (4.0, 7.0, 12.0)
+TILE = (1.6, 2.6)          # world-size of presence tiles of the two near planes
+PRESENT = (0.38, 0.5)      # fraction of tiles on which the near planes exist
+OCT_PX = (4.0, 8.0, 16.0, 32.0)
+OCT_W = (0.40, 0.28, 0.20, 0.12)
+
+
+def _hash01(ix, iy, salt):
+    h = (ix.astype(np.int64) * 73856093) ^ (iy.astype(np.int64) * 19349663) ^ (np.asarray(salt).astype(np.int64) * 83492791)
+    h = h.astype(np.uint64) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0x5BD1E995)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x27D4EB2F)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    return (h & np.uint64(0xFFFF)).astype(np.float32) * np.float32(1.0 / 65535.0)
+
+
+def _rot(yaw, pitch, roll):
+    y, p, r = np.deg2rad([yaw, pitch, roll])
+    Ry = np.array([[np.cos(y), 0, np.sin(y)], [0, 1, 0], [-np.sin(y), 0, np.cos(y)]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(p), -np.sin(p)], [0, np.sin(p), np.cos(p)]])
+    Rz = np.array([[np.cos(r), -np.sin(r), 0], [np.sin(r), np.cos(r), 0], [0, 0, 1]])
+    return Ry @ Rx @ Rz
+
+
+def _render(K, R, t, W, H, seed, focal):
+    """Ray-cast the scene from the camera X_c = R X_w + t."""
+    u, v = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    Kinv = np.linalg.inv(K)
+    d_c = np.stack([u, v, np.ones_like(u)], -1) @ Kinv.T          # rays in camera frame
+    d_w = d_c @ R                                                  # R^T applied to row vectors
+    o = -R.T @ t
+    hitX = np.zeros((H, W)); hitY = np.zeros((H, W)); plane = np.full((H, W), -1, np.int32)
+    for k, depth in enumerate(DEPTHS):
+        s = (depth - o[2]) / d_w[..., 2]
+        X = o[0] + s * d_w[..., 0]; Y = o[1] + s * d_w[..., 1]
+        if k < 2:
+            solid = _hash01(np.floor(X / TILE[k]), np.floor(Y / TILE[k]), seed * 7 + k) < PRESENT[k]
+        else:
+            solid = np.ones((H, W), bool)
+        take = (plane < 0) & solid & (s > 0)
+        hitX[take] = X[take]; hitY[take] = Y[take]; plane[take] = k
+    depth = np.asarray(DEPTHS)[np.clip(plane, 0, 2)]
+    val = np.zeros((H, W), np.float32)
+    for o_i, (px, w) in enumerate(zip(OCT_PX, OCT_W)):
+        cell = px * depth / focal                                   # world size of a px-sized cell at that depth
+        val += np.float32(w) * _hash01(np.floor(hitX / cell), np.floor(hitY / cell), seed * 131 + o_i * 17 + plane)
+    return val
+
+
+def _finish(val, rng):
+    img = 20.0 + 215.0 * val
+    p = np.pad(img, 1, mode="edge")
+    img = (p[:-2, 1:-1] + p[2:, 1:-1] + p[1:-1, :-2] + p[1:-1, 2:] + 4 * p[1:-1, 1:-1]) / 8.0
+    img = img + rng.normal(0.0, 2.0, img.shape)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def make_pair(seed, K, W=640, H=480, max_angle_deg=5.0, baseline=0.4):
+    """Returns img1, img2 (uint8 HxW), R_gt (3x3), t_gt (3x1 unit)."""
+    rng = np.random.default_rng(int(seed))
+    yaw, pitch, roll = rng.uniform(-max_angle_deg, max_angle_deg, 3)
+    R = _rot(yaw, pitch, roll)
+    tdir = rng.normal(size=3); tdir /= np.linalg.norm(tdir)
+    t = tdir * baseline
+    K = np.asarray(K, np.float64)
+    focal = 0.5 * (K[0, 0] + K[1, 1])
+    v1 = _render(K, np.eye(3), np.zeros(3), W, H, int(seed), focal)
+    v2 = _render(K, R, t, W, H, int(seed), focal)
+    return _finish(v1, rng), _finish(v2, rng), R, tdir.reshape(3, 1)
+
+
+def _job(args):
+    seed, K, W, H = args
+    return make_pair(seed, K, W, H)
+
+
+def make_batch(n, K, W=640, H=480, cfg=2, first=0, workers=1):
+    """n seeded pairs (seed = 1_000_003*cfg + index): imgs1, imgs2 [n,H,W], R [n,3,3], t [n,3,1]."""
+    seeds = [1_000_003 * cfg + first + i for i in range(n)]
+    jobs = [(s, np.asarray(K, np.float64), W, H) for s in seeds]
+    if workers > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            out = pool.map(_job, jobs, chunksize=max(1, n // (workers * 4)))
+    else:
+        out = [_job(j) for j in jobs]
+    i1 = np.stack([o[0] for o in out]); i2 = np.stack([o[1] for o in out])
+    R = np.stack([o[2] for o in out]); t = np.stack([o[3] for o in out])
+    return i1, i2, R, t
