@@ -1,0 +1,192 @@
+"""CPU tests (-m "not gpu"): pin the oracle against every known answer available
+offline -- cv::RNG known outputs, golden vectors generated from the reference's
+importable files, the reference's committed end-to-end result rows -- and check the
+oracle's own internal consistency (noise-free five-point, brute-force matcher
+restatement in numpy, pure-Python FAST on a small crop)."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_rng_known_outputs(oracle):
+    # cv::RNG((uint64)-1): SURVEY section 7 step 1
+    assert oracle.rng_stream(4) == [130063605, 3133359004, 2578348940, 925327173]
+
+
+def test_ransac_subsets_depend_only_on_M(oracle):
+    for M in (6, 50, 499, 500):
+        s = oracle.ransac_subsets(M, 200)
+        assert s.min() >= 0 and s.max() < M
+        assert all(len(set(r)) == 5 for r in s.tolist())
+        assert np.array_equal(s, oracle.ransac_subsets(M, 200))
+    st = oracle.rng_stream(5)
+    assert oracle.ransac_subsets(500, 1)[0].tolist() == [v % 500 for v in st]  # no duplicate among the first five draws
+
+
+def test_update_niters_known_values(oracle):
+    # 17 iterations at 80 % inliers, 218 at 50 %, 1000 at <= 30 %
+    assert oracle.update_niters(0.999, 0.2, 5, 1000) == 17
+    assert oracle.update_niters(0.999, 0.5, 5, 1000) == 218
+    assert oracle.update_niters(0.999, 0.7, 5, 1000) == 1000
+    assert oracle.update_niters(0.999, 0.0, 5, 1000) == 0
+    assert oracle.update_niters(0.999, 0.5, 5, 100) == 100
+
+
+def test_orb_layout(oracle):
+    L = oracle.orb_layout(640, 480, 1000)
+    assert list(L.quota) == [133, 121, 110, 100, 91, 83, 75, 68, 62, 57, 51, 49]
+    assert L.total == 1590354
+    assert list(oracle.orb_layout(640, 480, 4000).quota) == [534, 485, 441, 401, 365, 331, 301, 274, 249, 226, 206, 187]
+    assert oracle.orb_layout(1920, 1080, 4000).total == 10736237
+
+
+def test_pattern_table(oracle):
+    p = oracle.orb_pattern()
+    assert p.shape == (256, 4) and p.min() >= -13 and p.max() <= 13
+    assert p[0].tolist() == [8, -3, 9, 5] and p[1].tolist() == [4, 2, 7, -12] and p[255].tolist() == [-1, -6, 0, -11]
+
+
+def test_geometry_golden_vectors():
+    from relative_pose_estimation_amd import geometry as g
+    z = np.load(os.path.join(GOLD, "geometry_golden.npz"))
+    for i, a in enumerate(z["ang"]):
+        assert np.abs(g.euler_to_rotation(*a, "yup") - z["R_yup"][i]).max() < 1e-12
+        assert np.abs(g.euler_to_rotation(*a, "zyx") - z["R_zyx"][i]).max() < 1e-12
+        assert np.abs(np.array(g.rotation_to_euler(z["R_yup"][i], "yup")) - z["e_yup"][i]).max() < 1e-9
+        assert np.abs(np.array(g.rotation_to_euler(z["R_zyx"][i], "zyx")) - z["e_zyx"][i]).max() < 1e-9
+        assert abs(g.rotation_error(z["R_zyx"][i], z["R_zyx"][(i + 1) % 64]) - z["rot_err"][i]) < 1e-9
+        assert abs(g.translation_direction_error(z["tv"][i], z["tv"][(i + 7) % 64]) - z["t_err"][i]) < 1e-9
+    for (w, h), K in zip(z["sizes"], z["Ks"]):
+        assert np.abs(g.default_camera_matrix(int(w), int(h)) - K).max() < 1e-12
+
+
+def _rand_rot(rng, deg=10):
+    a = np.deg2rad(rng.uniform(-deg, deg, 3))
+    cx, sx, cy, sy, cz, sz = np.cos(a[0]), np.sin(a[0]), np.cos(a[1]), np.sin(a[1]), np.cos(a[2]), np.sin(a[2])
+    return (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+            @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+
+
+def test_five_point_recovers_true_essential(oracle):
+    rng = np.random.default_rng(0)
+    errs = []
+    for _ in range(100):
+        R = _rand_rot(rng); t = rng.normal(size=3); t /= np.linalg.norm(t)
+        X = np.c_[rng.uniform(-2, 2, (5, 2)), rng.uniform(4, 10, 5)]
+        x1 = X[:, :2] / X[:, 2:]; X2 = (R @ X.T).T + t; x2 = X2[:, :2] / X2[:, 2:]
+        Et = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
+        Et /= np.linalg.norm(Et)
+        Es = oracle.five_point(x1, x2)
+        assert 1 <= len(Es) <= 10
+        for E in Es:   # every model satisfies the epipolar constraints and the essential-matrix cubic constraints
+            assert abs(np.linalg.norm(E) - 1) < 1e-12
+            assert max(abs(np.r_[x2[i], 1] @ E @ np.r_[x1[i], 1]) for i in range(5)) < 1e-9
+            assert abs(np.linalg.det(E)) < 1e-6
+        errs.append(min(min(np.linalg.norm(E - Et), np.linalg.norm(E + Et)) for E in Es))
+    assert np.median(errs) < 1e-10 and max(errs) < 1e-5
+
+
+def _np_crosscheck(d1, d2, max_matches):
+    """App. A.2 restated in numpy/python (small cases only)."""
+    D = np.array([[bin(int.from_bytes(bytes(a ^ b), "little")).count("1") for b in d2] for a in d1]).reshape(len(d1), len(d2))
+    best = {}
+    for j in range(len(d2)):
+        i = int(np.argmin(D[:, j]))             # lowest i on ties
+        d = int(D[i, j])
+        if i not in best or d < best[i][0]:
+            best[i] = (d, j)
+    m = sorted(((d, i, j) for i, (d, j) in sorted(best.items())), key=lambda x: x[0])   # stable: ascending i inside equal d
+    return m[:max_matches]
+
+
+def test_matcher_matches_numpy_restatement(oracle):
+    rng = np.random.default_rng(3)
+    for n1, n2, bits in [(40, 37, 256), (64, 64, 12), (5, 90, 6), (90, 5, 6), (1, 1, 256)]:
+        d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8); d2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+        if bits < 256:   # few distinct descriptors => many ties
+            d1[:, bits // 8:] = 0; d2[:, bits // 8:] = 0
+        q, t, d = oracle.match_hamming(d1, d2, 25)
+        exp = _np_crosscheck(d1, d2, 25)
+        assert [(int(a), int(b), int(c)) for a, b, c in zip(d, q, t)] == exp
+    q, t, d = oracle.match_hamming(np.zeros((0, 32), np.uint8), d2, 10)
+    assert len(q) == 0
+
+
+def test_l2_matcher_ordering(oracle):
+    rng = np.random.default_rng(4)
+    a = rng.integers(0, 256, (50, 128)).astype(np.float32); b = rng.integers(0, 256, (60, 128)).astype(np.float32)
+    b[:10] = a[:10]
+    q, t, d = oracle.match_l2(a, b, 30)
+    assert np.all(np.diff(d) >= 0) and set(range(10)) <= set(q.tolist()) and np.all(d[:10] == 0)
+    D = np.sqrt(((a[:, None, :] - b[None, :, :]) ** 2).sum(-1))
+    for qi, ti, di in zip(q, t, d):
+        assert np.argmin(D[:, ti]) == qi and abs(D[qi, ti] - di) < 1e-3
+
+
+def _py_fast_score(img, x, y, thr):
+    circ = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    v = int(img[y, x]); d = [v - int(img[y + dy, x + dx]) for dx, dy in circ]
+    best = 0
+    for t in range(thr, 256):          # definition: largest threshold for which (x, y) is still a FAST-9 corner
+        ok = any(all(d[(k + j) % 16] > t for j in range(9)) or all(d[(k + j) % 16] < -t for j in range(9)) for k in range(16))
+        if not ok:
+            break
+        best = t
+    return best
+
+
+def test_fast_score_definition(oracle):
+    from relative_pose_estimation_amd import synthetic, geometry
+    img = synthetic.make_pair(5, geometry.default_camera_matrix(640, 480))[0][100:148, 200:264].copy()
+    sc = oracle.fast_score_map(img, 15)
+    assert (sc > 0).sum() > 10
+    for y in range(3, img.shape[0] - 3):
+        for x in range(3, img.shape[1] - 3):
+            assert sc[y, x] == _py_fast_score(img, x, y, 15), (x, y)
+    assert sc[:3].max() == 0 and sc[:, :3].max() == 0
+
+
+def test_orb_properties(oracle, K_vga):
+    from relative_pose_estimation_amd import synthetic
+    img = synthetic.make_pair(77, K_vga)[0]
+    kps, desc = oracle.orb_detect_and_compute(img, 1000)
+    L = oracle.orb_layout(640, 480, 1000)
+    assert 900 <= len(kps) <= 1064 and desc.shape == (len(kps), 32)
+    assert np.all(np.diff(kps["octave"]) >= 0)                       # level-major
+    for l in range(12):
+        k = kps[kps["octave"] == l]
+        assert np.all((k["lx"] >= 31) & (k["lx"] < L.w[l] - 31) & (k["ly"] >= 31) & (k["ly"] < L.h[l] - 31))
+        order = k["ly"].astype(np.int64) * 4096 + k["lx"]
+        assert np.all(np.diff(order) > 0)                            # raster order inside a level
+        assert len(k) >= min(L.quota[l], len(k))
+    assert np.all((kps["angle"] >= 0) & (kps["angle"] <= 360))
+    k2, d2 = oracle.orb_detect_and_compute(img, 1000)
+    assert np.array_equal(desc, d2)
+    # blur: constant image stays constant (kernel sums to 256), impulse response = outer(k, k)/2^16
+    assert np.all(oracle.blur_level(np.full((40, 50), 93, np.uint8)) == 93)
+    imp = np.zeros((21, 21), np.uint8); imp[10, 10] = 255
+    k = np.array([18, 34, 48, 56, 48, 34, 18])
+    assert np.array_equal(oracle.blur_level(imp)[7:14, 7:14], (np.outer(k, k) * 255 + 32768) >> 16)
+    assert abs(oracle.fast_atan2(1.0, 1.0) - 45) < 0.02 and abs(oracle.fast_atan2(-1.0, 0.0) - 270) < 0.02
+
+
+def test_forward_known_answers(oracle):
+    """Reference's committed result rows (evaluation_results.csv) for committed image
+    pairs: statistical agreement (stage-level parity with cv2 is unpinned)."""
+    from relative_pose_estimation_amd import geometry as g
+    z = np.load(os.path.join(GOLD, "forward_pairs.npz"))
+    conv = str(z["convention"])
+    for i in range(len(z["frames"])):
+        r = oracle.estimate_pose(z["img1"][i], z["img2"][i], z["K"], 4000, 500)   # pipeline.py:94-101 parameters
+        assert r["status"] == 0 and r["n_matches"] == 500
+        g1, g2 = z["gt1"][i], z["gt2"][i]
+        R_prev = g.euler_to_rotation(g1[5], g1[4], g1[3], conv)                    # batch_processor.py:82-89
+        R_new = R_prev @ r["R"]                                                    # batch_processor.py:97
+        err = g.rotation_error(R_new, g.euler_to_rotation(g2[5], g2[4], g2[3], conv))
+        assert err <= z["ref_rot_err"][i] + 0.5, (z["frames"][i], err, z["ref_rot_err"][i])
+        yaw, pitch, roll = g.rotation_to_euler(R_new, conv)
+        ref_roll, ref_pitch, ref_yaw = z["ref_est"][i]
+        assert abs(yaw - ref_yaw) < 1.5 and abs(pitch - ref_pitch) < 1.5 and abs(roll - ref_roll) < 1.5
