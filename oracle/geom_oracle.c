@@ -113,20 +113,41 @@ static double horner(const double *c, int n, double x)
     return acc;
 }
 
+/* Safeguarded Newton (bisection fallback) on a bracket [a,b] with a sign change of
+ * p (degree k); dp = p' (degree k-1).  sa = (p(a) > 0).  Iterates to f64
+ * resolution (next iterate == current) or 100 steps. */
+static double refine_root(const double *p, const double *dp, int k, double a, double b, int sa)
+{
+    double xl = sa ? b : a, xh = sa ? a : b;   /* p(xl) <= 0 < p(xh) in the s(v) = (v > 0) sense */
+    double rts = 0.5 * (a + b);
+    double dxold = fabs(b - a), dx = dxold;
+    double f = horner(p, k, rts), df = horner(dp, k - 1, rts);
+    for (int it = 0; it < 100; ++it) {
+        int bis = ((((rts - xh) * df - f) * ((rts - xl) * df - f)) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df));
+        double nr;
+        dxold = dx;
+        if (bis) { dx = 0.5 * (xh - xl); nr = xl + dx; }
+        else { dx = f / df; nr = rts - dx; }
+        if (nr == rts) break;
+        rts = nr;
+        f = horner(p, k, rts); df = horner(dp, k - 1, rts);
+        if (f > 0.0) xh = rts; else xl = rts;
+    }
+    return rts;
+}
+
 /* Real roots (ascending) of c[0]+c[1]x+...+c[n]x^n, c[n] != 0, n <= 10.
  * Nested-derivative isolation: the real roots of p^(k+1) split the line into
- * intervals on which p^(k) is monotone; each sign change is bisected to f64
- * resolution.  Sign convention: s(v) = (v > 0). */
+ * intervals on which p^(k) is monotone; every interval with a sign change
+ * (s(v) = (v > 0)) holds exactly one root, refined by safeguarded Newton. */
 static int poly_real_roots(const double *c, int n, double *roots)
 {
-    double d[11][11];      /* d[k] = coefficients of the polynomial of degree k in the chain */
+    double d[11][11];      /* d[k] = coefficients of the degree-k member of the derivative chain */
     double rts[2][11];
     int nr_prev = 0, cur = 0;
-    /* d[n] = p; d[k-1] = derivative of d[k] */
     for (int i = 0; i <= n; ++i) d[n][i] = c[i];
     for (int k = n; k >= 2; --k)
         for (int i = 0; i < k; ++i) d[k - 1][i] = d[k][i + 1] * (double)(i + 1);
-    /* degree 1 */
     rts[0][0] = -d[1][0] / d[1][1];
     nr_prev = 1; cur = 0;
     for (int k = 2; k <= n; ++k) {
@@ -146,20 +167,9 @@ static int poly_real_roots(const double *c, int n, double *roots)
             if (!(a < b)) continue;
             int sa = horner(p, k, a) > 0., sb = horner(p, k, b) > 0.;
             if (sa == sb) continue;
-            double lo = a, hi = b;
-            for (int it = 0; it < 200; ++it) {
-                double mid = 0.5 * (lo + hi);
-                if (!(mid > lo && mid < hi)) break;
-                int sm = horner(p, k, mid) > 0.;
-                if (sm == sa) lo = mid; else hi = mid;
-            }
-            out[nout++] = 0.5 * (lo + hi);
+            out[nout++] = refine_root(p, d[k - 1], k, a, b, sa);
         }
         nr_prev = nout; cur ^= 1;
-        if (nout == 0 && k < n) {
-            /* derivative chain without real critical points: p^(k) monotone-free;
-             * continue with an empty split (single interval) */
-        }
     }
     for (int i = 0; i < nr_prev; ++i) roots[i] = rts[cur][i];
     return nr_prev;

@@ -41,8 +41,29 @@ __device__ static double horner(const double *c, int n, double x)
     return acc;
 }
 
-// real roots (ascending) by nested-derivative isolation + bisection to f64 resolution
-__device__ static int poly_real_roots(const double *c, int n, double *roots)
+// Safeguarded Newton on a bracket with a sign change (same code path as the oracle).
+__device__ static double refine_root(const double *p, const double *dp, int k, double a, double b, int sa)
+{
+    double xl = sa ? b : a, xh = sa ? a : b;
+    double rts = 0.5 * (a + b);
+    double dxold = fabs(b - a), dx = dxold;
+    double f = horner(p, k, rts), df = horner(dp, k - 1, rts);
+    for (int it = 0; it < 100; ++it) {
+        int bis = ((((rts - xh) * df - f) * ((rts - xl) * df - f)) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df));
+        double nr;
+        dxold = dx;
+        if (bis) { dx = 0.5 * (xh - xl); nr = xl + dx; }
+        else { dx = f / df; nr = rts - dx; }
+        if (nr == rts) break;
+        rts = nr;
+        f = horner(p, k, rts); df = horner(dp, k - 1, rts);
+        if (f > 0.0) xh = rts; else xl = rts;
+    }
+    return rts;
+}
+
+// generic path (degree < 10 after leading-coefficient trimming: rare): dynamic indexing
+__device__ static int poly_real_roots_generic(const double *c, int n, double *roots)
 {
     double d[11][11];
     double rts[2][11];
@@ -69,19 +90,102 @@ __device__ static int poly_real_roots(const double *c, int n, double *roots)
             if (!(a < b)) continue;
             int sa = horner(p, k, a) > 0., sb = horner(p, k, b) > 0.;
             if (sa == sb) continue;
-            double lo = a, hi = b;
-            for (int it = 0; it < 200; ++it) {
-                double mid = 0.5 * (lo + hi);
-                if (!(mid > lo && mid < hi)) break;
-                int sm = horner(p, k, mid) > 0.;
-                if (sm == sa) lo = mid; else hi = mid;
-            }
-            out[nout++] = 0.5 * (lo + hi);
+            out[nout++] = refine_root(p, d[k - 1], k, a, b, sa);
         }
         nr_prev = nout; cur ^= 1;
     }
     for (int i = 0; i < nr_prev; ++i) roots[i] = rts[cur][i];
     return nr_prev;
+}
+
+// ---- degree-10 fast path: the polynomial of each chain level lives in registers
+// (static indexing); arithmetic identical to the generic path.
+template <int K>
+__device__ __forceinline__ double horner_s(const double (&c)[11], double x)
+{
+    double acc = c[K];
+#pragma unroll
+    for (int i = K - 1; i >= 0; --i) acc = acc * x + c[i];
+    return acc;
+}
+
+template <int K>
+__device__ __forceinline__ double refine_root_s(const double (&p)[11], const double (&dp)[11], double a, double b, int sa)
+{
+    double xl = sa ? b : a, xh = sa ? a : b;
+    double rts = 0.5 * (a + b);
+    double dxold = fabs(b - a), dx = dxold;
+    double f = horner_s<K>(p, rts), df = horner_s<K - 1>(dp, rts);
+    for (int it = 0; it < 100; ++it) {
+        int bis = ((((rts - xh) * df - f) * ((rts - xl) * df - f)) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df));
+        double nr;
+        dxold = dx;
+        if (bis) { dx = 0.5 * (xh - xl); nr = xl + dx; }
+        else { dx = f / df; nr = rts - dx; }
+        if (nr == rts) break;
+        rts = nr;
+        f = horner_s<K>(p, rts); df = horner_s<K - 1>(dp, rts);
+        if (f > 0.0) xh = rts; else xl = rts;
+    }
+    return rts;
+}
+
+template <int K>
+__device__ __forceinline__ int roots_level(const double (&c)[11], const double *crit, int nr_prev, double *out)
+{
+    double p[11], dp[11];
+#pragma unroll
+    for (int i = 0; i <= 10; ++i) p[i] = c[i];
+#pragma unroll
+    for (int kk = 10; kk > K; --kk)
+#pragma unroll
+        for (int i = 0; i < kk; ++i) p[i] = p[i + 1] * (double)(i + 1);
+#pragma unroll
+    for (int i = 0; i < K; ++i) dp[i] = p[i + 1] * (double)(i + 1);
+    double mx = 0.;
+#pragma unroll
+    for (int i = 0; i < K; ++i) { double a = fabs(p[i]); if (a > mx) mx = a; }
+    double R = 1. + mx / fabs(p[K]);
+    if (!(R < 1e12)) R = 1e12;
+    int nout = 0;
+    for (int iv = 0; iv <= nr_prev; ++iv) {
+        double a = (iv == 0) ? -R : crit[iv - 1];
+        double b = (iv == nr_prev) ? R : crit[iv];
+        if (a < -R) a = -R;
+        if (b > R) b = R;
+        if (!(a < b)) continue;
+        int sa = horner_s<K>(p, a) > 0., sb = horner_s<K>(p, b) > 0.;
+        if (sa == sb) continue;
+        out[nout++] = refine_root_s<K>(p, dp, a, b, sa);
+    }
+    return nout;
+}
+
+__device__ static int poly_real_roots10(const double (&c)[11], double *roots)
+{
+    double ra[11], rb[11];
+    {
+        double p[11];
+#pragma unroll
+        for (int i = 0; i <= 10; ++i) p[i] = c[i];
+#pragma unroll
+        for (int kk = 10; kk > 1; --kk)
+#pragma unroll
+            for (int i = 0; i < kk; ++i) p[i] = p[i + 1] * (double)(i + 1);
+        ra[0] = -p[0] / p[1];
+    }
+    int n = 1;
+    n = roots_level<2>(c, ra, n, rb);
+    n = roots_level<3>(c, rb, n, ra);
+    n = roots_level<4>(c, ra, n, rb);
+    n = roots_level<5>(c, rb, n, ra);
+    n = roots_level<6>(c, ra, n, rb);
+    n = roots_level<7>(c, rb, n, ra);
+    n = roots_level<8>(c, ra, n, rb);
+    n = roots_level<9>(c, rb, n, ra);
+    n = roots_level<10>(c, ra, n, rb);
+    for (int i = 0; i < n; ++i) roots[i] = rb[i];
+    return n;
 }
 
 // Nister five-point solver (five-point.cpp EMEstimatorCallback::runKernel restated;
@@ -188,7 +292,7 @@ __device__ static int five_point_dev(const double *x1, const double *x2, double 
     int n = 10;
     for (; n > 1; --n) if (fabs(c10[n]) > DBL_EPSILON) break;
     double roots[10];
-    int nroots = poly_real_roots(c10, n, roots);
+    int nroots = (n == 10) ? poly_real_roots10(c10, roots) : poly_real_roots_generic(c10, n, roots);
     int count = 0;
     for (int ri = 0; ri < nroots && count < 10; ++ri) {
         double z = roots[ri];

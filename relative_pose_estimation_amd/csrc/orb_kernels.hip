@@ -16,7 +16,7 @@
 #include "rpe_internal.h"
 
 #define TW 64
-#define TH 16
+#define TH 64
 
 __constant__ signed char c_pattern[256 * 4] = {
 #include "brief_pattern.inc"
@@ -32,59 +32,87 @@ void rpe_orb_upload_disc(const signed char *disc, int n)
 }
 
 // ---------------------------------------------------------------- pyramid
-// one thread = 4 consecutive destination pixels of level l
+// Workgroup = 64x64 destination tile of level l.  The source footprint in level l-1
+// (<= 74 rows x 80 bytes, bounds derived arithmetically so the loads do not depend on
+// the coefficient tables) is staged in LDS with aligned dword loads -- ~5.9 KB in
+// flight per workgroup; one lane = 4 rows x 4 destination pixels.
+#define PYR_ROWS 74
+#define PYR_DW 20
 __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDeviceLayout lay, const int *__restrict__ coef, int l)
 {
+    __shared__ unsigned s_src[PYR_ROWS * PYR_DW];
     const RpeLevel &S = lay.lv[l - 1];
     const RpeLevel &D = lay.lv[l];
-    int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x4 >= D.pitch || y >= D.h) return;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
     uint8_t *base = pyr + (long long)blockIdx.z * lay.stride;
     const uint8_t *src = base + S.off;
     const int *xo = coef + D.coef_off, *xa = xo + D.w, *yo = xa + D.w, *ya = yo + D.h;
-    int oy = yo[y], b1 = ya[y], b0 = 256 - b1;
-    int oy1 = min(oy + 1, S.h - 1);
-    const uint8_t *r0 = src + (long long)oy * S.pitch, *r1 = src + (long long)oy1 * S.pitch;
-    unsigned out = 0;
+    // conservative footprint: floor(scale*x0) <= xo[x0] (scale >= 1), checked on the host
+    const int a0 = ((int)(((long long)x0 * S.w) / D.w)) & ~3;
+    const int sy0 = (int)(((long long)y0 * S.h) / D.h);
+    const int tx = tid & 15, tyb = tid >> 4;
+    const int x4 = x0 + 4 * tx;
+    int o[4], a1[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int x = x4 + j;
-        unsigned v = 0;
-        if (x < D.w) {
-            int o = xo[x], a1 = xa[x], a0 = 256 - a1;
-            int o1 = min(o + 1, S.w - 1);
-            unsigned h0 = (unsigned)(a0 * r0[o] + a1 * r0[o1]);
-            unsigned h1 = (unsigned)(a0 * r1[o] + a1 * r1[o1]);
-            v = ((unsigned)b0 * h0 + (unsigned)b1 * h1 + 32768u) >> 16;
-        }
-        out |= v << (8 * j);
+    for (int j = 0; j < 4; ++j) { int x = min(x4 + j, D.w - 1); o[j] = xo[x]; a1[j] = xa[x]; }
+    int oy[4], b1[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) { int y = min(y0 + tyb + 16 * rr, D.h - 1); oy[rr] = yo[y]; b1[rr] = ya[y]; }
+    for (int i = tid; i < PYR_ROWS * PYR_DW; i += 256) {
+        int r = i / PYR_DW, c = i - r * PYR_DW;
+        int y = min(sy0 + r, S.h - 1);
+        int x = min(a0 + 4 * c, S.pitch - 4);
+        s_src[i] = *(const unsigned *)(src + (long long)y * S.pitch + x);
     }
-    *(unsigned *)(base + D.off + (long long)y * D.pitch + x4) = out;
+    __syncthreads();
+    if (x4 >= D.pitch) return;
+    const uint8_t *sb = (const uint8_t *)s_src;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int y = y0 + tyb + 16 * rr;
+        if (y >= D.h) break;
+        const int b0 = 256 - b1[rr];
+        const uint8_t *r0 = sb + (oy[rr] - sy0) * (PYR_DW * 4) - a0;
+        const uint8_t *r1 = sb + (min(oy[rr] + 1, S.h - 1) - sy0) * (PYR_DW * 4) - a0;
+        unsigned out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned v = 0;
+            if (x4 + j < D.w) {
+                int o0 = o[j], o1 = min(o0 + 1, S.w - 1), a0c = 256 - a1[j];
+                unsigned h0 = (unsigned)(a0c * r0[o0] + a1[j] * r0[o1]);
+                unsigned h1 = (unsigned)(a0c * r1[o0] + a1[j] * r1[o1]);
+                v = ((unsigned)b0 * h0 + (unsigned)b1[rr] * h1 + 32768u) >> 16;
+            }
+            out |= v << (8 * j);
+        }
+        *(unsigned *)(base + D.off + (long long)y * D.pitch + x4) = out;
+    }
 }
 
 void rpe_launch_pyramid(rpe_handle *h, int n_img)
 {
     for (int l = 1; l < RPE_NLEVELS; ++l) {
         const RpeLevel &D = h->lay.lv[l];
-        dim3 grid((D.pitch / 4 + 63) / 64, (D.h + 3) / 4, n_img);
+        dim3 grid((D.pitch + 63) / 64, (D.h + 63) / 64, n_img);
         hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, h->stream, h->d_pyr, h->lay, h->d_coef, l);
     }
 }
 
 // ------------------------------------------------------------------- FAST
-// Tile 64x16 pixels; LDS input tile 22 rows x 72 bytes (halo 3 rows, 4 columns for
-// dword alignment).  Phase 1: 4 pixels per thread, compass quick test, survivors
-// appended to an LDS candidate list.  Phase 2: the list is processed densely
-// (one candidate per thread per trip): 16 ring differences, window-9 min/max via
-// min3/max3, score = max(A, B) - 1 written to an LDS output tile.
+// Tile 64x64 pixels; LDS input tile 70 rows x 72 bytes (halo 3 rows, 4 columns for
+// dword alignment; ~5 KB in flight per workgroup).  Phase 1: 16 pixels per lane,
+// compass quick test, survivors appended to an LDS candidate list.  Phase 2: the
+// list is processed densely (one candidate per lane per trip): 16 ring differences,
+// window-9 min/max via min3/max3, score = max(A, B) - 1 into an LDS output tile.
 __device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
 __device__ __forceinline__ int imax3(int a, int b, int c) { return max(a, max(b, c)); }
 
 __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ score,
                                                           RpeDeviceLayout lay, const RpeTile *__restrict__ tiles)
 {
-    __shared__ unsigned s_in[22 * 18];
+    __shared__ unsigned s_in[(TH + 6) * 18];
     __shared__ unsigned s_out[TH * 16];
     __shared__ unsigned short s_cand[TW * TH];
     __shared__ int s_ncand;
@@ -96,16 +124,18 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t *__restri
     const long long ibase = (long long)blockIdx.y * lay.stride + L.off;
     const uint8_t *src = pyr + ibase;
     if (tid == 0) s_ncand = 0;
-    for (int i = tid; i < 22 * 18; i += 256) {
+    for (int i = tid; i < (TH + 6) * 18; i += 256) {
         int r = i / 18, c = i - r * 18;
         int y = min(max(y0 - 3 + r, 0), hgt - 1);
         int x = min(max(x0 - 4 + 4 * c, 0), pitch - 4);
         s_in[i] = *(const unsigned *)(src + (long long)y * pitch + x);
     }
-    s_out[tid] = 0;
+    for (int i = tid; i < TH * 16; i += 256) s_out[i] = 0;
     __syncthreads();
-    {
-        const int tx = tid & 15, ty = tid >> 4;
+    const int tx = tid & 15, tyb = tid >> 4;
+#pragma unroll
+    for (int rr = 0; rr < TH / 16; ++rr) {
+        const int ty = tyb + 16 * rr;
         const int r = ty + 3;
         unsigned cdw = s_in[r * 18 + tx + 1], ldw = s_in[r * 18 + tx], rdw = s_in[r * 18 + tx + 2];
         unsigned top = s_in[(r - 3) * 18 + tx + 1], bot = s_in[(r + 3) * 18 + tx + 1];
@@ -155,11 +185,12 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t *__restri
         if (s > thr) ((uint8_t *)s_out)[ly * 64 + lx] = (uint8_t)(s - 1);
     }
     __syncthreads();
-    {
-        const int tx = tid & 15, ty = tid >> 4;
+#pragma unroll
+    for (int rr = 0; rr < TH / 16; ++rr) {
+        const int ty = tyb + 16 * rr;
         int px = x0 + 4 * tx, py = y0 + ty;
         if (py < hgt && px < pitch)
-            *(unsigned *)(score + ibase + (long long)py * pitch + px) = s_out[tid];
+            *(unsigned *)(score + ibase + (long long)py * pitch + px) = s_out[ty * 16 + tx];
     }
 }
 
@@ -171,12 +202,12 @@ void rpe_launch_fast(rpe_handle *h, int n_img)
 
 // -------------------------------------------------------------------- NMS
 // 3x3 strict-maximum suppression on the score map, 31-px border filter, and a
-// 256-bin histogram of the surviving scores per (image, level).
+// 256-bin histogram of the surviving scores per (image, level).  64x64 tiles.
 __global__ __launch_bounds__(256) void nms_hist_kernel(const uint8_t *__restrict__ score, uint8_t *__restrict__ nms,
                                                         unsigned *__restrict__ hist, RpeDeviceLayout lay,
                                                         const RpeTile *__restrict__ tiles)
 {
-    __shared__ unsigned s_in[18 * 18];
+    __shared__ unsigned s_in[(TH + 2) * 18];
     __shared__ unsigned s_hist[256];
     const int tid = threadIdx.x;
     const RpeTile t = tiles[blockIdx.x];
@@ -186,42 +217,46 @@ __global__ __launch_bounds__(256) void nms_hist_kernel(const uint8_t *__restrict
     const long long ibase = (long long)blockIdx.y * lay.stride + L.off;
     const uint8_t *src = score + ibase;
     s_hist[tid] = 0;
-    for (int i = tid; i < 18 * 18; i += 256) {
+    for (int i = tid; i < (TH + 2) * 18; i += 256) {
         int r = i / 18, c = i - r * 18;
         int y = min(max(y0 - 1 + r, 0), hgt - 1);
         int x = min(max(x0 - 4 + 4 * c, 0), pitch - 4);
         s_in[i] = *(const unsigned *)(src + (long long)y * pitch + x);
     }
     __syncthreads();
-    const int tx = tid & 15, ty = tid >> 4;
-    const int py = y0 + ty;
-    unsigned out = 0;
-    if (py >= RPE_EDGE && py < hgt - RPE_EDGE) {
-        unsigned long long rows[3][2];
+    const int tx = tid & 15, tyb = tid >> 4;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            unsigned a = s_in[(ty + r) * 18 + tx], b = s_in[(ty + r) * 18 + tx + 1], c = s_in[(ty + r) * 18 + tx + 2];
-            rows[r][0] = (unsigned long long)a | ((unsigned long long)b << 32);   // bytes x-4 .. x+3
-            rows[r][1] = (unsigned long long)b | ((unsigned long long)c << 32);   // bytes x .. x+7
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int px = x0 + 4 * tx + j;
-            int v = (int)((rows[1][1] >> (8 * j)) & 255);
-            if (v == 0 || px < RPE_EDGE || px >= w - RPE_EDGE) continue;
-            bool keep = true;
+    for (int rr = 0; rr < TH / 16; ++rr) {
+        const int ty = tyb + 16 * rr;
+        const int py = y0 + ty;
+        unsigned out = 0;
+        if (py >= RPE_EDGE && py < hgt - RPE_EDGE && s_in[(ty + 1) * 18 + tx + 1] != 0) {
+            unsigned long long rows[3][2];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                int lft = (int)((rows[r][0] >> (8 * (3 + j))) & 255);
-                int mid = (int)((rows[r][1] >> (8 * j)) & 255);
-                int rgt = (int)((rows[r][1] >> (8 * (j + 1))) & 255);
-                keep = keep && v > lft && v > rgt && (r == 1 || v > mid);
+                unsigned a = s_in[(ty + r) * 18 + tx], b = s_in[(ty + r) * 18 + tx + 1], c = s_in[(ty + r) * 18 + tx + 2];
+                rows[r][0] = (unsigned long long)a | ((unsigned long long)b << 32);   // bytes x-4 .. x+3
+                rows[r][1] = (unsigned long long)b | ((unsigned long long)c << 32);   // bytes x .. x+7
             }
-            if (keep) { out |= (unsigned)v << (8 * j); atomicAdd(&s_hist[v], 1u); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int px = x0 + 4 * tx + j;
+                int v = (int)((rows[1][1] >> (8 * j)) & 255);
+                if (v == 0 || px < RPE_EDGE || px >= w - RPE_EDGE) continue;
+                bool keep = true;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    int lft = (int)((rows[r][0] >> (8 * (3 + j))) & 255);
+                    int mid = (int)((rows[r][1] >> (8 * j)) & 255);
+                    int rgt = (int)((rows[r][1] >> (8 * (j + 1))) & 255);
+                    keep = keep && v > lft && v > rgt && (r == 1 || v > mid);
+                }
+                if (keep) { out |= (unsigned)v << (8 * j); atomicAdd(&s_hist[v], 1u); }
+            }
         }
+        int px = x0 + 4 * tx;
+        if (py < hgt && px < pitch) *(unsigned *)(nms + ibase + (long long)py * pitch + px) = out;
     }
-    int px = x0 + 4 * tx;
-    if (py < hgt && px < pitch) *(unsigned *)(nms + ibase + (long long)py * pitch + px) = out;
     __syncthreads();
     unsigned c = s_hist[tid];
     if (c) atomicAdd(&hist[((long long)blockIdx.y * RPE_NLEVELS + t.level) * 256 + tid], c);
@@ -526,8 +561,10 @@ __device__ __forceinline__ int refl101(int p, int n) { p = p < 0 ? -p : p; retur
 __global__ __launch_bounds__(256) void blur_kernel(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ dst,
                                                     RpeDeviceLayout lay, const RpeTile *__restrict__ tiles)
 {
-    __shared__ uint8_t s_in[22 * 72];
-    __shared__ unsigned short s_h[22 * 64];
+    // 64x64 tile; input 70 rows x 72 bytes (x0-4 .. x0+67) loaded as aligned dwords; rows
+    // are reflected at load time, the <=3 reflected columns per side are patched in LDS.
+    __shared__ unsigned s_in[(TH + 6) * 18];
+    __shared__ uint2 s_h[(TH + 6) * 16];          // horizontal pass: 4 x u16 per entry
     const int tid = threadIdx.x;
     const RpeTile t = tiles[blockIdx.x];
     const RpeLevel &L = lay.lv[t.level];
@@ -535,30 +572,56 @@ __global__ __launch_bounds__(256) void blur_kernel(const uint8_t *__restrict__ p
     const int x0 = t.tx, y0 = t.ty;
     const long long ibase = (long long)blockIdx.y * lay.stride + L.off;
     const uint8_t *src = pyr + ibase;
-    for (int i = tid; i < 22 * 70; i += 256) {
-        int r = i / 70, c = i - r * 70;
-        int y = refl101(y0 - 3 + r, hgt), x = refl101(x0 - 3 + c, w);
-        y = min(max(y, 0), hgt - 1); x = min(max(x, 0), w - 1);
-        s_in[r * 72 + c] = src[(long long)y * pitch + x];
+    for (int i = tid; i < (TH + 6) * 18; i += 256) {
+        int r = i / 18, c = i - r * 18;
+        int y = refl101(y0 - 3 + r, hgt);
+        y = min(max(y, 0), hgt - 1);
+        int x = min(max(x0 - 4 + 4 * c, 0), pitch - 4);
+        s_in[i] = *(const unsigned *)(src + (long long)y * pitch + x);
     }
     __syncthreads();
-    for (int i = tid; i < 22 * 64; i += 256) {
-        int r = i >> 6, c = i & 63;
-        const uint8_t *p = s_in + r * 72 + c;
-        unsigned s = 18u * p[0] + 34u * p[1] + 48u * p[2] + 56u * p[3] + 48u * p[4] + 34u * p[5] + 18u * p[6];
-        s_h[i] = (unsigned short)s;
+    uint8_t *sb = (uint8_t *)s_in;
+    if (x0 == 0) {               // columns -1,-2,-3 <- 1,2,3
+        for (int i = tid; i < (TH + 6) * 3; i += 256) { int r = i / 3, k = i - r * 3 + 1; sb[r * 72 + 4 - k] = sb[r * 72 + 4 + k]; }
+    }
+    if (x0 + 64 + 3 >= w && x0 < w) {   // columns w, w+1, w+2 <- w-2, w-3, w-4
+        for (int i = tid; i < (TH + 6) * 3; i += 256) {
+            int r = i / 3, k = i - r * 3;
+            int cd = w + k - x0 + 4, cs = w - 2 - k - x0 + 4;
+            if (cd < 72 && cs >= 0) sb[r * 72 + cd] = sb[r * 72 + cs];
+        }
     }
     __syncthreads();
-    const int tx = tid & 15, ty = tid >> 4;
-    unsigned out = 0;
+    for (int i = tid; i < (TH + 6) * 16; i += 256) {
+        int r = i >> 4, c = i & 15;
+        unsigned a = s_in[r * 18 + c], b = s_in[r * 18 + c + 1], d = s_in[r * 18 + c + 2];
+        unsigned p[12];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned short *p = s_h + ty * 64 + 4 * tx + j;
-        unsigned s = 18u * p[0] + 34u * p[64] + 48u * p[128] + 56u * p[192] + 48u * p[256] + 34u * p[320] + 18u * p[384];
-        out |= ((s + 32768u) >> 16) << (8 * j);
+        for (int k = 0; k < 4; ++k) { p[k] = (a >> (8 * k)) & 255; p[4 + k] = (b >> (8 * k)) & 255; p[8 + k] = (d >> (8 * k)) & 255; }
+        unsigned o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = 18u * p[j + 1] + 34u * p[j + 2] + 48u * p[j + 3] + 56u * p[j + 4] + 48u * p[j + 5] + 34u * p[j + 6] + 18u * p[j + 7];
+        s_h[i] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
     }
-    int px = x0 + 4 * tx, py = y0 + ty;
-    if (py < hgt && px < pitch) *(unsigned *)(dst + ibase + (long long)py * pitch + px) = out;
+    __syncthreads();
+    const int tx = tid & 15, tyb = tid >> 4;
+    const unsigned kk[7] = {18u, 34u, 48u, 56u, 48u, 34u, 18u};
+#pragma unroll
+    for (int rr = 0; rr < TH / 16; ++rr) {
+        const int ty = tyb + 16 * rr;
+        unsigned acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            uint2 v = s_h[(ty + r) * 16 + tx];
+            acc[0] += kk[r] * (v.x & 0xFFFF); acc[1] += kk[r] * (v.x >> 16);
+            acc[2] += kk[r] * (v.y & 0xFFFF); acc[3] += kk[r] * (v.y >> 16);
+        }
+        unsigned out = ((acc[0] + 32768u) >> 16) | (((acc[1] + 32768u) >> 16) << 8) | (((acc[2] + 32768u) >> 16) << 16) |
+                       (((acc[3] + 32768u) >> 16) << 24);
+        int px = x0 + 4 * tx, py = y0 + ty;
+        if (py < hgt && px < pitch) *(unsigned *)(dst + ibase + (long long)py * pitch + px) = out;
+    }
 }
 
 void rpe_launch_blur(rpe_handle *h, int n_img)

@@ -130,10 +130,10 @@ static int build_tables(rpe_handle *h)
     std::vector<RpeTile> full, fast;
     for (int l = 0; l < RPE_NLEVELS; ++l) {
         const RpeLevel &v = L.lv[l];
-        for (int y = 0; y < v.h; y += 16)
+        for (int y = 0; y < v.h; y += 64)
             for (int x = 0; x < v.pitch; x += 64) full.push_back({(short)l, (short)x, (short)y, 0});
         if (v.w > 2 * RPE_EDGE && v.h > 2 * RPE_EDGE)
-            for (int y = 28; y < v.h - 28; y += 16)
+            for (int y = 28; y < v.h - 28; y += 64)
                 for (int x = 28; x < v.w - 28; x += 64) fast.push_back({(short)l, (short)x, (short)y, 0});
     }
     h->n_tiles_full = (int)full.size(); h->n_tiles_fast = (int)fast.size();
@@ -149,6 +149,22 @@ static int build_tables(rpe_handle *h)
         int *xo = coef.data() + D.coef_off, *xa = xo + D.w, *yo = xa + D.w, *ya = yo + D.h;
         lin_coeffs(S.w, D.w, xo, xa);
         lin_coeffs(S.h, D.h, yo, ya);
+    }
+    // the resize kernel stages a fixed 74-row x 80-byte source footprint per 64x64 tile,
+    // anchored at floor(scale * tile origin); verify the tables fit it for every tile
+    for (int l = 1; l < RPE_NLEVELS; ++l) {
+        const RpeLevel &S = L.lv[l - 1], &D = L.lv[l];
+        const int *xo = coef.data() + D.coef_off, *yo = xo + 2 * D.w;
+        for (int x0 = 0; x0 < D.w; x0 += 64) {
+            int a0 = ((int)(((long long)x0 * S.w) / D.w)) & ~3, xl = x0 + 63 < D.w ? x0 + 63 : D.w - 1;
+            int hi = xo[xl] + 1 < S.w ? xo[xl] + 1 : S.w - 1;
+            if (xo[x0] < a0 || hi - a0 >= 80) { h->err = "pyramid footprint bound violated (x)"; return RPE_ERR_INVALID; }
+        }
+        for (int y0 = 0; y0 < D.h; y0 += 64) {
+            int s0 = (int)(((long long)y0 * S.h) / D.h), yl = y0 + 63 < D.h ? y0 + 63 : D.h - 1;
+            int hi = yo[yl] + 1 < S.h ? yo[yl] + 1 : S.h - 1;
+            if (yo[y0] < s0 || hi - s0 >= 74) { h->err = "pyramid footprint bound violated (y)"; return RPE_ERR_INVALID; }
+        }
     }
     DM(h, h->d_coef, ncoef);
     HIPCHK(h, hipMemcpy(h->d_coef, coef.data(), sizeof(int) * (size_t)ncoef, hipMemcpyHostToDevice));
