@@ -100,75 +100,143 @@ void rpe_launch_pyramid(rpe_handle *h, int n_img)
     }
 }
 
-// ------------------------------------------------------------------- FAST
-// Tile 64x64 pixels; LDS input tile 70 rows x 72 bytes (halo 3 rows, 4 columns for
-// dword alignment; ~5 KB in flight per workgroup).  Phase 1: 16 pixels per lane,
-// compass quick test, survivors appended to an LDS candidate list.  Phase 2: the
-// list is processed densely (one candidate per lane per trip): 16 ring differences,
-// window-9 min/max via min3/max3, score = max(A, B) - 1 into an LDS output tile.
+// ------------------------------------------------------------- FAST + NMS
+// Fused FAST-9/16 score + 3x3 non-maximum suppression + border filter + histogram.
+// Tile = 64x64 output pixels; scores are needed on 66x66, pixels on 72x72 (halo 3+1
+// rows, 4 columns => dword aligned).  ~5 KB of loads in flight per workgroup.
+//  phase 1: every dword group (4 px) of the 66x72 score area: OpenCV's pair test on the
+//           4 compass + 4 diagonal ring pixels with class bits (darker=1 / brighter=2):
+//           a 9-arc contains one pixel of every opposite pair, so
+//           (c0|c8)&(c4|c12)&(c2|c10)&(c6|c14) != 0 is necessary; survivors are appended
+//           to an LDS list with one wave-aggregated LDS atomic per wave.
+//  phase 2: list processed densely: 16 ring differences, window-9 min/max via
+//           min3/max3, score = max(A,B)-1 (0 if not a corner) into the LDS score tile.
+//  phase 3: strict 3x3 maximum on the LDS score tile, 31-px border filter
+//           (KeyPointsFilter::runByImageBorder), 256-bin histogram, NMS map to HBM.
 __device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
 __device__ __forceinline__ int imax3(int a, int b, int c) { return max(a, max(b, c)); }
+typedef short short2_t __attribute__((ext_vector_type(2)));
+// Bresenham circle of radius 3 (fast.cpp), compile-time offsets
+static constexpr int CIRC_DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+static constexpr int CIRC_DY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
 
-__global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ score,
-                                                          RpeDeviceLayout lay, const RpeTile *__restrict__ tiles)
+#define FS_ROWS 66          // score rows / columns region (y0-1 .. y0+64)
+__global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ nms,
+                                                        unsigned *__restrict__ hist, RpeDeviceLayout lay,
+                                                        const RpeTile *__restrict__ tiles)
 {
-    __shared__ unsigned s_in[(TH + 6) * 18];
-    __shared__ unsigned s_out[TH * 16];
-    __shared__ unsigned short s_cand[TW * TH];
+    __shared__ unsigned s_in[72 * 18];              // pixels  y0-4 .. y0+67, x0-4 .. x0+67
+    __shared__ unsigned s_sc[FS_ROWS * 18];         // scores  y0-1 .. y0+64, x0-4 .. x0+67
+    __shared__ unsigned s_nms[64 * 16];             // output tile
+    __shared__ unsigned short s_cand[FS_ROWS * 72];
+    __shared__ unsigned s_hist[256];
     __shared__ int s_ncand;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const RpeTile t = tiles[blockIdx.x];
     const RpeLevel &L = lay.lv[t.level];
     const int w = L.w, hgt = L.h, pitch = L.pitch, thr = lay.fast_thr;
     const int x0 = t.tx, y0 = t.ty;
     const long long ibase = (long long)blockIdx.y * lay.stride + L.off;
+    const int tx = tid & 15, tyb = tid >> 4;
+    // tiles that cannot contain a keypoint after the border filter: write zeros only
+    const bool live = w > 2 * RPE_EDGE && hgt > 2 * RPE_EDGE && x0 < w - RPE_EDGE && x0 + 64 > RPE_EDGE &&
+                      y0 < hgt - RPE_EDGE && y0 + 64 > RPE_EDGE;
+    if (!live) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            int px = x0 + 4 * tx, py = y0 + tyb + 16 * rr;
+            if (py < hgt && px < pitch) *(unsigned *)(nms + ibase + (long long)py * pitch + px) = 0u;
+        }
+        return;
+    }
     const uint8_t *src = pyr + ibase;
     if (tid == 0) s_ncand = 0;
-    for (int i = tid; i < (TH + 6) * 18; i += 256) {
+    s_hist[tid] = 0;
+    for (int i = tid; i < 72 * 18; i += 256) {
         int r = i / 18, c = i - r * 18;
-        int y = min(max(y0 - 3 + r, 0), hgt - 1);
+        int y = min(max(y0 - 4 + r, 0), hgt - 1);
         int x = min(max(x0 - 4 + 4 * c, 0), pitch - 4);
         s_in[i] = *(const unsigned *)(src + (long long)y * pitch + x);
     }
-    for (int i = tid; i < TH * 16; i += 256) s_out[i] = 0;
+    for (int i = tid; i < FS_ROWS * 18; i += 256) s_sc[i] = 0;
+    for (int i = tid; i < 64 * 16; i += 256) s_nms[i] = 0;
     __syncthreads();
-    const int tx = tid & 15, tyb = tid >> 4;
+    // ---- phase 1 (packed 16-bit SWAR: even / odd pixels of the dword group in one VGPR each)
+    const unsigned T1 = (unsigned)(thr + 1) * 0x00010001u, T0 = (unsigned)thr * 0x00010001u;
+    for (int g0 = 0; g0 < FS_ROWS * 18; g0 += 256) {
+        const int g = min(g0 + tid, FS_ROWS * 18 - 1);
+        const bool gvalid = g0 + tid < FS_ROWS * 18;      // loop is wave-uniform (shuffles below)
+        const int ry = g / 18, c = g - ry * 18;
+        const int ri = ry + 3;                       // input row of this score row
+        const int py = y0 - 1 + ry;
+        const int cl = max(c - 1, 0), cr = min(c + 1, 17);
+        const unsigned cdw = s_in[ri * 18 + c], ldw = s_in[ri * 18 + cl], rdw = s_in[ri * 18 + cr];
+        const unsigned upl = s_in[(ri - 2) * 18 + cl], upc = s_in[(ri - 2) * 18 + c], upr = s_in[(ri - 2) * 18 + cr];
+        const unsigned dnl = s_in[(ri + 2) * 18 + cl], dnc = s_in[(ri + 2) * 18 + c], dnr = s_in[(ri + 2) * 18 + cr];
+        unsigned mask2[2];
 #pragma unroll
-    for (int rr = 0; rr < TH / 16; ++rr) {
-        const int ty = tyb + 16 * rr;
-        const int r = ty + 3;
-        unsigned cdw = s_in[r * 18 + tx + 1], ldw = s_in[r * 18 + tx], rdw = s_in[r * 18 + tx + 2];
-        unsigned top = s_in[(r - 3) * 18 + tx + 1], bot = s_in[(r + 3) * 18 + tx + 1];
-        unsigned long long lo64 = (unsigned long long)ldw | ((unsigned long long)cdw << 32);
-        unsigned long long hi64 = (unsigned long long)cdw | ((unsigned long long)rdw << 32);
-        const int py = y0 + ty;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int px = x0 + 4 * tx + j;
-            int v = (cdw >> (8 * j)) & 255;
-            int d0 = v - (int)((bot >> (8 * j)) & 255);
-            int d8 = v - (int)((top >> (8 * j)) & 255);
-            int d4 = v - (int)((hi64 >> (8 * (3 + j))) & 255);
-            int d12 = v - (int)((lo64 >> (8 * (1 + j))) & 255);
-            bool skip = (abs(d0) <= thr && abs(d8) <= thr) || (abs(d4) <= thr && abs(d12) <= thr);
-            bool valid = px >= 3 && px < w - 3 && py >= 3 && py < hgt - 3;
-            if (valid && !skip) {
-                int idx = atomicAdd(&s_ncand, 1);
-                s_cand[idx] = (unsigned short)((ty << 6) | (4 * tx + j));
-            }
+        for (int par = 0; par < 2; ++par) {
+            // v_perm_b32 picks bytes (sh+par, sh+par+2) of {hi:lo} into the low bytes of two 16-bit lanes
+#define PK2(hi, lo, sh) __builtin_bit_cast(short2_t, __builtin_amdgcn_perm((hi), (lo), 0x0c000c00u | (unsigned)((sh) + par) | ((unsigned)((sh) + par + 2) << 16)))
+            const short2_t ce = PK2(0u, cdw, 0);
+            short2_t d[8];
+            d[0] = ce - PK2(0u, s_in[(ri + 3) * 18 + c], 0);   // ( 0, 3)
+            d[1] = ce - PK2(0u, s_in[(ri - 3) * 18 + c], 0);   // ( 0,-3)
+            d[2] = ce - PK2(rdw, cdw, 3);                      // ( 3, 0)
+            d[3] = ce - PK2(cdw, ldw, 1);                      // (-3, 0)
+            d[4] = ce - PK2(dnr, dnc, 2);                      // ( 2, 2)
+            d[5] = ce - PK2(upc, upl, 2);                      // (-2,-2)
+            d[6] = ce - PK2(upr, upc, 2);                      // ( 2,-2)
+            d[7] = ce - PK2(dnc, dnl, 2);                      // (-2, 2)
+#undef PK2
+            // opposite pairs: (0,1) (2,3) (4,5) (6,7)
+            short2_t bmin = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(d[0], d[1]), __builtin_elementwise_max(d[2], d[3])),
+                                                      __builtin_elementwise_min(__builtin_elementwise_max(d[4], d[5]), __builtin_elementwise_max(d[6], d[7])));
+            short2_t dmax = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(d[0], d[1]), __builtin_elementwise_min(d[2], d[3])),
+                                                      __builtin_elementwise_max(__builtin_elementwise_min(d[4], d[5]), __builtin_elementwise_min(d[6], d[7])));
+            // bmin > thr  <=>  bmin - (thr+1) >= 0 ;  dmax < -thr  <=>  dmax + thr < 0
+            const unsigned u = __builtin_bit_cast(unsigned, bmin - __builtin_bit_cast(short2_t, T1));
+            const unsigned q = __builtin_bit_cast(unsigned, dmax + __builtin_bit_cast(short2_t, T0));
+            mask2[par] = (~u | q) & 0x80008000u;
+        }
+        unsigned candmask = ((mask2[0] >> 15) & 1u) | (((mask2[1] >> 15) & 1u) << 1) | (((mask2[0] >> 31) & 1u) << 2) | (((mask2[1] >> 31) & 1u) << 3);
+        // scores are consumed on [30, w-30) x [30, h-30) only (NMS of border-filtered pixels)
+        const int pxb = x0 - 4 + 4 * c;
+        const int xlo = max(x0 - 1, RPE_EDGE - 1), xhi = min(x0 + 64, w - RPE_EDGE);   // valid px range (inclusive)
+        unsigned vmask = 0xFu;
+        if (pxb < xlo) vmask &= 0xFu << min(xlo - pxb, 4);
+        if (pxb + 3 > xhi) vmask &= 0xFu >> min(pxb + 3 - xhi, 4);
+        if (!(gvalid && py >= RPE_EDGE - 1 && py < hgt - RPE_EDGE + 1)) vmask = 0;
+        candmask &= vmask;
+        // wave-aggregated append: 4 ballots + mbcnt prefix counts (VALU/SALU only), one LDS
+        // atomic per wave; list order is irrelevant
+        const unsigned long long b0 = __ballot(candmask & 1u), b1 = __ballot(candmask & 2u),
+                                 b2 = __ballot(candmask & 4u), b3 = __ballot(candmask & 8u);
+        if (b0 | b1 | b2 | b3) {
+            const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_ncand, n0 + n1 + n2 + n3);
+            base = __shfl(base, 0);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const unsigned short code = (unsigned short)((ry << 7) | (4 * c));
+            if (candmask & 1u) s_cand[base + __popcll(b0 & lt)] = code;
+            if (candmask & 2u) s_cand[base + n0 + __popcll(b1 & lt)] = code + 1;
+            if (candmask & 4u) s_cand[base + n0 + n1 + __popcll(b2 & lt)] = code + 2;
+            if (candmask & 8u) s_cand[base + n0 + n1 + n2 + __popcll(b3 & lt)] = code + 3;
         }
     }
     __syncthreads();
+    // ---- phase 2
     const int ncand = s_ncand;
     const uint8_t *sb = (const uint8_t *)s_in;
     for (int i = tid; i < ncand; i += 256) {
-        int c = s_cand[i];
-        int lx = c & 63, ly = c >> 6;
-        const uint8_t *p = sb + (ly + 3) * 72 + lx + 4;
-        int v = p[0];
+        const int cc = s_cand[i];
+        const int bx = cc & 127, ry = cc >> 7;
+        const uint8_t *p = sb + (ry + 3) * 72 + bx;
+        const int v = p[0];
         int d[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) d[k] = v - (int)p[(int)c_circ[2 * k + 1] * 72 + (int)c_circ[2 * k]];
+        for (int k = 0; k < 16; ++k) d[k] = v - (int)p[CIRC_DY[k] * 72 + CIRC_DX[k]];
         int m3[16], x3[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -181,93 +249,44 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t *__restri
             A = max(A, imin3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]));
             Bm = min(Bm, imax3(x3[k], x3[(k + 3) & 15], x3[(k + 6) & 15]));
         }
-        int s = max(A, -Bm);
-        if (s > thr) ((uint8_t *)s_out)[ly * 64 + lx] = (uint8_t)(s - 1);
+        const int s = max(A, -Bm);
+        if (s > thr) ((uint8_t *)s_sc)[ry * 72 + bx] = (uint8_t)(s - 1);
+    }
+    __syncthreads();
+    // ---- phase 3: NMS + border filter + histogram, again over the candidate list
+    // (only pixels that went through phase 2 can hold a score)
+    const uint8_t *sc = (const uint8_t *)s_sc;
+    for (int i = tid; i < ncand; i += 256) {
+        const int cc = s_cand[i];
+        const int bx = cc & 127, ry = cc >> 7;
+        const int px = x0 - 4 + bx, py = y0 - 1 + ry;
+        if (bx < 4 || bx >= 68 || ry < 1 || ry > 64) continue;                       // halo pixels are not outputs
+        if (px < RPE_EDGE || px >= w - RPE_EDGE || py < RPE_EDGE || py >= hgt - RPE_EDGE) continue;
+        const uint8_t *q = sc + ry * 72 + bx;
+        const int v = q[0];
+        if (v == 0) continue;
+        const bool keep = v > q[-1] && v > q[1] && v > q[-73] && v > q[-72] && v > q[-71] && v > q[71] && v > q[72] && v > q[73];
+        if (keep) { ((uint8_t *)s_nms)[(ry - 1) * 64 + (bx - 4)] = (uint8_t)v; atomicAdd(&s_hist[v], 1u); }
     }
     __syncthreads();
 #pragma unroll
-    for (int rr = 0; rr < TH / 16; ++rr) {
+    for (int rr = 0; rr < 4; ++rr) {
         const int ty = tyb + 16 * rr;
-        int px = x0 + 4 * tx, py = y0 + ty;
-        if (py < hgt && px < pitch)
-            *(unsigned *)(score + ibase + (long long)py * pitch + px) = s_out[ty * 16 + tx];
+        const int px = x0 + 4 * tx, py = y0 + ty;
+        if (py < hgt && px < pitch) *(unsigned *)(nms + ibase + (long long)py * pitch + px) = s_nms[ty * 16 + tx];
     }
-}
-
-void rpe_launch_fast(rpe_handle *h, int n_img)
-{
-    hipLaunchKernelGGL(fast_score_kernel, dim3(h->n_tiles_fast, n_img), dim3(256), 0, h->stream,
-                       h->d_pyr, h->d_bufA, h->lay, h->d_tiles_fast);
-}
-
-// -------------------------------------------------------------------- NMS
-// 3x3 strict-maximum suppression on the score map, 31-px border filter, and a
-// 256-bin histogram of the surviving scores per (image, level).  64x64 tiles.
-__global__ __launch_bounds__(256) void nms_hist_kernel(const uint8_t *__restrict__ score, uint8_t *__restrict__ nms,
-                                                        unsigned *__restrict__ hist, RpeDeviceLayout lay,
-                                                        const RpeTile *__restrict__ tiles)
-{
-    __shared__ unsigned s_in[(TH + 2) * 18];
-    __shared__ unsigned s_hist[256];
-    const int tid = threadIdx.x;
-    const RpeTile t = tiles[blockIdx.x];
-    const RpeLevel &L = lay.lv[t.level];
-    const int w = L.w, hgt = L.h, pitch = L.pitch;
-    const int x0 = t.tx, y0 = t.ty;
-    const long long ibase = (long long)blockIdx.y * lay.stride + L.off;
-    const uint8_t *src = score + ibase;
-    s_hist[tid] = 0;
-    for (int i = tid; i < (TH + 2) * 18; i += 256) {
-        int r = i / 18, c = i - r * 18;
-        int y = min(max(y0 - 1 + r, 0), hgt - 1);
-        int x = min(max(x0 - 4 + 4 * c, 0), pitch - 4);
-        s_in[i] = *(const unsigned *)(src + (long long)y * pitch + x);
-    }
-    __syncthreads();
-    const int tx = tid & 15, tyb = tid >> 4;
-#pragma unroll
-    for (int rr = 0; rr < TH / 16; ++rr) {
-        const int ty = tyb + 16 * rr;
-        const int py = y0 + ty;
-        unsigned out = 0;
-        if (py >= RPE_EDGE && py < hgt - RPE_EDGE && s_in[(ty + 1) * 18 + tx + 1] != 0) {
-            unsigned long long rows[3][2];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                unsigned a = s_in[(ty + r) * 18 + tx], b = s_in[(ty + r) * 18 + tx + 1], c = s_in[(ty + r) * 18 + tx + 2];
-                rows[r][0] = (unsigned long long)a | ((unsigned long long)b << 32);   // bytes x-4 .. x+3
-                rows[r][1] = (unsigned long long)b | ((unsigned long long)c << 32);   // bytes x .. x+7
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int px = x0 + 4 * tx + j;
-                int v = (int)((rows[1][1] >> (8 * j)) & 255);
-                if (v == 0 || px < RPE_EDGE || px >= w - RPE_EDGE) continue;
-                bool keep = true;
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    int lft = (int)((rows[r][0] >> (8 * (3 + j))) & 255);
-                    int mid = (int)((rows[r][1] >> (8 * j)) & 255);
-                    int rgt = (int)((rows[r][1] >> (8 * (j + 1))) & 255);
-                    keep = keep && v > lft && v > rgt && (r == 1 || v > mid);
-                }
-                if (keep) { out |= (unsigned)v << (8 * j); atomicAdd(&s_hist[v], 1u); }
-            }
-        }
-        int px = x0 + 4 * tx;
-        if (py < hgt && px < pitch) *(unsigned *)(nms + ibase + (long long)py * pitch + px) = out;
-    }
-    __syncthreads();
     unsigned c = s_hist[tid];
     if (c) atomicAdd(&hist[((long long)blockIdx.y * RPE_NLEVELS + t.level) * 256 + tid], c);
 }
 
-void rpe_launch_nms(rpe_handle *h, int n_img)
+void rpe_launch_fast(rpe_handle *h, int n_img)
 {
     hipMemsetAsync(h->d_hist, 0, sizeof(unsigned) * 256 * RPE_NLEVELS * (size_t)n_img, h->stream);
-    hipLaunchKernelGGL(nms_hist_kernel, dim3(h->n_tiles_full, n_img), dim3(256), 0, h->stream,
-                       h->d_bufA, h->d_bufB, h->d_hist, h->lay, h->d_tiles_full);
+    hipLaunchKernelGGL(fast_nms_kernel, dim3(h->n_tiles_full, n_img), dim3(256), 0, h->stream,
+                       h->d_pyr, h->d_bufB, h->d_hist, h->lay, h->d_tiles_full);
 }
+
+void rpe_launch_nms(rpe_handle *h, int n_img) { (void)h; (void)n_img; }   // fused into fast_nms_kernel
 
 // ------------------------------------------------- block-wide exclusive scan
 __device__ __forceinline__ int block_excl_scan(int v, int *s_wave /*[5]*/, int &total)
