@@ -57,10 +57,8 @@ def cpu_baseline(i1, i2, K, nfeatures, max_matches, sample):
     cores on a bounded sample of the same workload."""
     from oracle import oracle
     oracle.build()
-    cores = os.cpu_count() or 1
-    share = os.environ.get("RPE_CPU_SHARE")
-    if share:
-        cores = min(cores, int(share))
+    # a 1-GPU box owns a 16-core share of the host (RPE_CPU_SHARE overrides)
+    cores = min(os.cpu_count() or 1, int(os.environ.get("RPE_CPU_SHARE", "16")))
     n = min(sample, len(i1))
     threads = min(cores, n)
     t0 = time.perf_counter()
@@ -81,9 +79,10 @@ def main():
     ap.add_argument("--max-matches", type=int, default=500)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--cpu-sample", type=int, default=48)
+    ap.add_argument("--cpu-sample", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gen-workers", type=int, default=0)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of the N>1 path)")
     ap.add_argument("--data-cache", default="", help="npz file to load/save the synthetic batch (keeps forks out of profiled runs)")
     args = ap.parse_args()
 
@@ -100,8 +99,11 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     W, H, B = args.width, args.height, args.batch
     K = geometry.default_camera_matrix(W, H)
@@ -118,7 +120,12 @@ def main():
         if cache:
             np.savez(cache, i1=i1, i2=i2, R=Rgt, t=tgt)
 
-    eng = _capi.Engine(W, H, max_batch=B, nfeatures=args.nfeatures, max_matches=args.max_matches, device=local_rank)
+    ndev = _capi.load().rpe_device_count()
+    device = local_rank % max(ndev, 1)
+    gather_dev = None
+    if dist is not None and args.dist_backend == "nccl":
+        gather_dev = torch.device("cuda", local_rank)
+    eng = _capi.Engine(W, H, max_batch=B, nfeatures=args.nfeatures, max_matches=args.max_matches, device=device)
     d1 = eng.upload(i1); d2 = eng.upload(i2)     # inputs resident in HBM before the timed region
     eng.set_profiling(True)
 
@@ -126,14 +133,15 @@ def main():
         eng.synchronize()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if gather_dev is not None:
+                torch.cuda.synchronize()
 
     def step():
         eng.enqueue_batch_device(d1, d2, B, K)
         R, t, inl, nm, st = eng.fetch_results(B)
         rec = sharding.pack_records(R, t, inl, st, nm, first_pair=rank * B)
         if dist is not None:
-            rec = sharding.gather_pose_records(rec, B, device=torch.device("cuda", local_rank))
+            rec = sharding.gather_pose_records(rec, B, device=gather_dev)
         return rec, (R, t, inl, nm, st)
 
     for _ in range(args.warmup):
@@ -148,7 +156,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev if gather_dev is not None else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -541,11 +541,34 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
+// deterministic sin/cos (fdlibm kernel polynomials); identical op order to the oracle
+__device__ __forceinline__ void det_sincos(double x, double &sn, double &cs)
+{
+    const double PIO2_HI = 1.57079632673412561417e+00, PIO2_LO = 6.07710050650619224932e-11;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    int k = (int)(x * 0.63661977236758134308 + 0.5);
+    double r = (x - (double)k * PIO2_HI) - (double)k * PIO2_LO;
+    double z = r * r;
+    double ps = S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))));
+    double pc = C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6))));
+    double s = r + (r * z) * ps;
+    double c = (1.0 - 0.5 * z) + (z * z) * pc;
+    switch (k & 3) {
+    case 0: sn = s;  cs = c;  break;
+    case 1: sn = c;  cs = -s; break;
+    case 2: sn = -s; cs = -c; break;
+    default: sn = -c; cs = s; break;
+    }
+}
+
 // orb.cpp ICAngles: one wave per keypoint, lanes stride over the 749 disc pixels,
 // integer moments reduced with wave shuffles.
 __global__ __launch_bounds__(256) void ic_angle_kernel(const uint8_t *__restrict__ pyr, const unsigned *__restrict__ kp_xy,
                                                         const int *__restrict__ kp_count, float *__restrict__ kp_angle,
-                                                        RpeDeviceLayout lay)
+                                                        float2 *__restrict__ kp_cs, RpeDeviceLayout lay)
 {
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6), img = blockIdx.y;
@@ -563,13 +586,21 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(const uint8_t *__restrict
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
-    if (lane == 0) kp_angle[(long long)img * lay.kcap + k] = fast_atan2_deg((float)m01, (float)m10);
+    if (lane == 0) {
+        const float angle = fast_atan2_deg((float)m01, (float)m10);
+        kp_angle[(long long)img * lay.kcap + k] = angle;
+        // steering terms of computeOrbDescriptors, once per keypoint: a = cos, b = sin (f32)
+        const float ang = angle * (float)(3.141592653589793238462643383279502884 / 180.0);
+        double sn, cs;
+        det_sincos((double)ang, sn, cs);
+        kp_cs[(long long)img * lay.kcap + k] = make_float2((float)cs, (float)sn);
+    }
 }
 
 void rpe_launch_angle(rpe_handle *h, int n_img)
 {
     hipLaunchKernelGGL(ic_angle_kernel, dim3((h->lay.kcap + 3) / 4, n_img), dim3(256), 0, h->stream,
-                       h->d_pyr, h->d_kp_xy, h->d_kp_count, h->d_kp_angle, h->lay);
+                       h->d_pyr, h->d_kp_xy, h->d_kp_count, h->d_kp_angle, h->d_kp_cs, h->lay);
 }
 
 // ------------------------------------------------------------------- blur
@@ -650,32 +681,9 @@ void rpe_launch_blur(rpe_handle *h, int n_img)
 }
 
 // --------------------------------------------------------------- describe
-// deterministic sin/cos (fdlibm kernel polynomials); identical op order to the oracle
-__device__ __forceinline__ void det_sincos(double x, double &sn, double &cs)
-{
-    const double PIO2_HI = 1.57079632673412561417e+00, PIO2_LO = 6.07710050650619224932e-11;
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
-                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
-                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    int k = (int)(x * 0.63661977236758134308 + 0.5);
-    double r = (x - (double)k * PIO2_HI) - (double)k * PIO2_LO;
-    double z = r * r;
-    double ps = S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))));
-    double pc = C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6))));
-    double s = r + (r * z) * ps;
-    double c = (1.0 - 0.5 * z) + (z * z) * pc;
-    switch (k & 3) {
-    case 0: sn = s;  cs = c;  break;
-    case 1: sn = c;  cs = -s; break;
-    case 2: sn = -s; cs = -c; break;
-    default: sn = -c; cs = s; break;
-    }
-}
-
 // orb.cpp computeOrbDescriptors (WTA_K = 2): 32 lanes per keypoint, lane = byte index.
 __global__ __launch_bounds__(256) void describe_kernel(const uint8_t *__restrict__ blur, const unsigned *__restrict__ kp_xy,
-                                                        const float2 *__restrict__ kp_pt, const float *__restrict__ kp_angle,
+                                                        const float2 *__restrict__ kp_pt, const float2 *__restrict__ kp_cs,
                                                         const int *__restrict__ kp_count, uint8_t *__restrict__ desc,
                                                         RpeDeviceLayout lay)
 {
@@ -687,10 +695,8 @@ __global__ __launch_bounds__(256) void describe_kernel(const uint8_t *__restrict
     const RpeLevel &L = lay.lv[l];
     const float2 pt = kp_pt[g];
     const float sc = 1.f / L.scale;
-    const float ang = kp_angle[g] * (float)(3.141592653589793238462643383279502884 / 180.0);
-    double sn, cs;
-    det_sincos((double)ang, sn, cs);
-    const float a = (float)cs, b = (float)sn;
+    const float2 csn = kp_cs[g];
+    const float a = csn.x, b = csn.y;
     const int cx = __float2int_rn(pt.x * sc), cy = __float2int_rn(pt.y * sc);
     const int pitch = L.pitch;
     const uint8_t *center = blur + (long long)img * lay.stride + L.off + (long long)cy * pitch + cx;
@@ -711,5 +717,5 @@ __global__ __launch_bounds__(256) void describe_kernel(const uint8_t *__restrict
 void rpe_launch_describe(rpe_handle *h, int n_img)
 {
     hipLaunchKernelGGL(describe_kernel, dim3((h->lay.kcap + 7) / 8, n_img), dim3(256), 0, h->stream,
-                       h->d_bufA, h->d_kp_xy, h->d_kp_pt, h->d_kp_angle, h->d_kp_count, h->d_desc, h->lay);
+                       h->d_bufA, h->d_kp_xy, h->d_kp_pt, h->d_kp_cs, h->d_kp_count, h->d_desc, h->lay);
 }

@@ -248,7 +248,7 @@ static int alloc_workspace(rpe_handle *h)
     DM(h, h->d_cand_xy, NI * L.cand_total); DM(h, h->d_cand_resp, NI * L.cand_total);
     DM(h, h->d_cand_count, NI * RPE_NLEVELS);
     DM(h, h->d_kp_xy, NI * L.kcap); DM(h, h->d_kp_resp, NI * L.kcap); DM(h, h->d_kp_angle, NI * L.kcap);
-    DM(h, h->d_kp_pt, NI * L.kcap); DM(h, h->d_kp_count, NI);
+    DM(h, h->d_kp_pt, NI * L.kcap); DM(h, h->d_kp_cs, NI * L.kcap); DM(h, h->d_kp_count, NI);
     DM(h, h->d_desc, NI * L.kcap * 32);
     HIPCHK(h, hipMemset(h->d_kp_pt, 0, NI * L.kcap * sizeof(float2)));
     HIPCHK(h, hipMemset(h->d_kp_count, 0, NI * sizeof(int)));
@@ -308,7 +308,7 @@ extern "C" void rpe_destroy(rpe_handle *h)
     if (h->stream) hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_tiles_full, h->d_tiles_fast, h->d_coef, h->d_pyr, h->d_bufA, h->d_bufB, h->d_stage1, h->d_stage2,
                     h->d_hist, h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_angle,
-                    h->d_kp_pt, h->d_kp_count, h->d_desc, h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2,
+                    h->d_kp_pt, h->d_kp_cs, h->d_kp_count, h->d_desc, h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2,
                     h->d_subsets, h->d_nit_denom, h->d_nit_round, h->d_rstate, h->d_n1, h->d_n2, h->d_found, h->d_models,
                     h->d_nmodels, h->d_mask, h->d_R, h->d_t, h->d_E, h->d_inliers, h->d_status, h->d_K};
     for (void *p : ptrs) if (p) hipFree(p);

@@ -73,6 +73,7 @@ struct rpe_handle {
     unsigned *d_kp_xy = nullptr;      // [img][kcap]  x | y<<12 | level<<24
     float *d_kp_resp = nullptr, *d_kp_angle = nullptr;
     float2 *d_kp_pt = nullptr;
+    float2 *d_kp_cs = nullptr;        // [img][kcap] (cos, sin) of the keypoint angle
     int *d_kp_count = nullptr;        // [img]
     uint8_t *d_desc = nullptr;        // [img][kcap][32]
     // matching
