@@ -169,3 +169,69 @@ def test_error_statuses(capi, K_vga):
     with pytest.raises(RuntimeError, match="Could not compute descriptors"):
         pe.estimate(flat[0], flat[0])
     pe.close()
+
+
+@pytest.mark.parametrize("W,H,nf", [(848, 478, 4000), (1920, 1080, 2000), (640, 480, 4000)])
+def test_other_sizes_and_reference_defaults(capi, oracle, W, H, nf):
+    """reference defaults (nfeatures=4000, pose_estimator.py:25), the phone-data frame size
+    (848x478: pitch != width) and the Salah HD size (BASELINE config 3 resolution)."""
+    from relative_pose_estimation_amd import synthetic, geometry
+    K = geometry.default_camera_matrix(W, H)
+    i1, i2, Rgt, _ = synthetic.make_batch(1, K, W, H, cfg=5)
+    e = capi.Engine(W, H, max_batch=1, nfeatures=nf, max_matches=500)
+    kps, desc, cnt = e.orb_detect_and_compute(np.concatenate([i1, i2]))
+    for n, img in enumerate((i1[0], i2[0])):
+        ko, do = oracle.orb_detect_and_compute(img, nf)
+        assert cnt[n] == len(ko)
+        kg = kps[n, :cnt[n]]
+        assert np.array_equal(kg["lx"], ko["lx"]) and np.array_equal(kg["ly"], ko["ly"]) and np.array_equal(kg["octave"], ko["octave"])
+        assert np.array_equal(kg["angle"].view(np.uint32), ko["angle"].view(np.uint32))
+        assert np.array_equal(desc[n, :cnt[n]], do)
+    R, t, inl, nm, st = e.estimate_batch(i1, i2, K)
+    r = oracle.estimate_pose(i1[0], i2[0], K, nf, 500)
+    assert st[0] == r["status"] and nm[0] == r["n_matches"] and inl[0] == r["inliers"]
+    assert np.array_equal(R[0], r["R"]) and np.array_equal(t[0], r["t"])
+    e.close()
+
+
+def test_reference_image_pairs(capi, oracle):
+    """the reference's own committed frames (tests/golden/forward_pairs.npz) through the drop-in
+    class: GPU == oracle bit for bit, and the forward known-answer bound of the CSV rows."""
+    import os
+    from relative_pose_estimation_amd import PoseEstimator, geometry as g
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "forward_pairs.npz"))
+    pe = PoseEstimator(z["K"])                       # reference defaults: ORB, Hamming, 500, 4000
+    for i in range(len(z["frames"])):
+        d = pe.estimate_with_debug(z["img1"][i], z["img2"][i])
+        r = oracle.estimate_pose(z["img1"][i], z["img2"][i], z["K"], 4000, 500)
+        assert np.array_equal(d["R"], r["R"]) and np.array_equal(d["t"], r["t"]) and d["inliers"] == r["inliers"]
+        assert d["num_matches"] == r["n_matches"] and d["pts1"].shape == (d["num_matches"], 2) and d["vp_used"] is False
+        g1, g2 = z["gt1"][i], z["gt2"][i]
+        R_new = g.euler_to_rotation(g1[5], g1[4], g1[3], "yup") @ d["R"]
+        err = g.rotation_error(R_new, g.euler_to_rotation(g2[5], g2[4], g2[3], "yup"))
+        assert err <= z["ref_rot_err"][i] + 0.5
+    R, t = pe.estimate(z["img1"][0], z["img2"][0])
+    assert R.shape == (3, 3) and t.shape == (3, 1) and abs(np.linalg.norm(t) - 1) < 1e-9
+    pe.close()
+
+
+def test_batch_is_order_independent_and_deterministic(eng1000, pairs, K_vga):
+    i1, i2, _, _ = pairs
+    a = eng1000.estimate_batch(i1, i2, K_vga)
+    b = eng1000.estimate_batch(i1[::-1].copy(), i2[::-1].copy(), K_vga)
+    c = eng1000.estimate_batch(i1, i2, K_vga)
+    for x, y, zc in zip(a, b, c):
+        assert np.array_equal(x, y[::-1]) and np.array_equal(x, zc)
+
+
+def test_ragged_batch_with_failures(capi, oracle, pairs, K_vga):
+    """a flat image (no descriptors) and a low-texture pair inside a batch do not disturb the others"""
+    i1, i2, _, _ = pairs
+    flat = np.full((480, 640), 90, np.uint8)
+    b1 = np.stack([i1[0], flat, i1[1]]); b2 = np.stack([i2[0], i2[1], flat])
+    e = capi.Engine(640, 480, max_batch=3, nfeatures=1000)
+    R, t, inl, nm, st = e.estimate_batch(b1, b2, K_vga)
+    assert list(st) == [0, capi.PAIR_NO_DESCRIPTORS, capi.PAIR_NO_DESCRIPTORS]
+    r = oracle.estimate_pose(i1[0], i2[0], K_vga, 1000, 500)
+    assert np.array_equal(R[0], r["R"]) and inl[0] == r["inliers"]
+    e.close()
