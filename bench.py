@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gen-workers", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=1, help="split the batch over S engine handles (S HIP streams) so latency-bound stages overlap")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of the N>1 path)")
     ap.add_argument("--data-cache", default="", help="npz file to load/save the synthetic batch (keeps forks out of profiled runs)")
     args = ap.parse_args()
@@ -125,20 +126,28 @@ def main():
     gather_dev = None
     if dist is not None and args.dist_backend == "nccl":
         gather_dev = torch.device("cuda", local_rank)
-    eng = _capi.Engine(W, H, max_batch=B, nfeatures=args.nfeatures, max_matches=args.max_matches, device=device)
-    d1 = eng.upload(i1); d2 = eng.upload(i2)     # inputs resident in HBM before the timed region
-    eng.set_profiling(True)
+    S = max(1, args.streams)
+    bounds = [sharding.shard_bounds(B, s, S) for s in range(S)]
+    engs = [_capi.Engine(W, H, max_batch=hi - lo, nfeatures=args.nfeatures, max_matches=args.max_matches, device=device)
+            for lo, hi in bounds]
+    eng = engs[0]
+    dbuf = [(e.upload(i1[lo:hi]), e.upload(i2[lo:hi])) for e, (lo, hi) in zip(engs, bounds)]   # inputs resident in HBM
+    for e in engs:
+        e.set_profiling(True)
 
     def barrier():
-        eng.synchronize()
+        for e in engs:
+            e.synchronize()
         if dist is not None:
             dist.barrier()
             if gather_dev is not None:
                 torch.cuda.synchronize()
 
     def step():
-        eng.enqueue_batch_device(d1, d2, B, K)
-        R, t, inl, nm, st = eng.fetch_results(B)
+        for e, (a, b), (lo, hi) in zip(engs, dbuf, bounds):
+            e.enqueue_batch_device(a, b, hi - lo, K)
+        parts = [e.fetch_results(hi - lo) for e, (lo, hi) in zip(engs, bounds)]
+        R, t, inl, nm, st = (np.concatenate([p[k] for p in parts]) for k in range(5))
         rec = sharding.pack_records(R, t, inl, st, nm, first_pair=rank * B)
         if dist is not None:
             rec = sharding.gather_pose_records(rec, B, device=gather_dev)
@@ -151,8 +160,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rec, local = step()
-        for k, v in eng.stage_ms().items():
-            stage_acc[k] = stage_acc.get(k, 0.0) + v
+        for e in engs:
+            for k, v in e.stage_ms().items():
+                stage_acc[k] = stage_acc.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -211,7 +221,8 @@ def main():
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
 
-    eng.close()
+    for e in engs:
+        e.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -115,7 +115,7 @@ static double horner(const double *c, int n, double x)
 
 /* Safeguarded Newton (bisection fallback) on a bracket [a,b] with a sign change of
  * p (degree k); dp = p' (degree k-1).  sa = (p(a) > 0).  Iterates to f64
- * resolution (next iterate == current) or 100 steps. */
+ * resolution (see the convergence test) or 100 steps. */
 static double refine_root(const double *p, const double *dp, int k, double a, double b, int sa)
 {
     double xl = sa ? b : a, xh = sa ? a : b;   /* p(xl) <= 0 < p(xh) in the s(v) = (v > 0) sense */
@@ -128,7 +128,8 @@ static double refine_root(const double *p, const double *dp, int k, double a, do
         dxold = dx;
         if (bis) { dx = 0.5 * (xh - xl); nr = xl + dx; }
         else { dx = f / df; nr = rts - dx; }
-        if (nr == rts) break;
+        /* converged: fixed point or relative step below 2.3e-13 (~1000 ulp) */
+        if (nr == rts || fabs(nr - rts) <= 2.3e-13 * fabs(nr)) { rts = nr; break; }
         rts = nr;
         f = horner(p, k, rts); df = horner(dp, k - 1, rts);
         if (f > 0.0) xh = rts; else xl = rts;

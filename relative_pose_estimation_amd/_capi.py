@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librpe_amd.so")
+LIB_PATH = os.environ.get("RPE_LIB", os.path.join(_HERE, "librpe_amd.so"))   # RPE_LIB: diagnostic builds only
 
 ABI_VERSION = 1
 ORB_LEVELS = 12

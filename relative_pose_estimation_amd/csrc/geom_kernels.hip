@@ -54,7 +54,7 @@ __device__ static double refine_root(const double *p, const double *dp, int k, d
         dxold = dx;
         if (bis) { dx = 0.5 * (xh - xl); nr = xl + dx; }
         else { dx = f / df; nr = rts - dx; }
-        if (nr == rts) break;
+        if (nr == rts || fabs(nr - rts) <= 2.3e-13 * fabs(nr)) { rts = nr; break; }
         rts = nr;
         f = horner(p, k, rts); df = horner(dp, k - 1, rts);
         if (f > 0.0) xh = rts; else xl = rts;
@@ -122,7 +122,7 @@ __device__ __forceinline__ double refine_root_s(const double (&p)[11], const dou
         dxold = dx;
         if (bis) { dx = 0.5 * (xh - xl); nr = xl + dx; }
         else { dx = f / df; nr = rts - dx; }
-        if (nr == rts) break;
+        if (nr == rts || fabs(nr - rts) <= 2.3e-13 * fabs(nr)) { rts = nr; break; }
         rts = nr;
         f = horner_s<K>(p, rts); df = horner_s<K - 1>(dp, rts);
         if (f > 0.0) xh = rts; else xl = rts;
@@ -190,8 +190,18 @@ __device__ static int poly_real_roots10(const double (&c)[11], double *roots)
 
 // Nister five-point solver (five-point.cpp EMEstimatorCallback::runKernel restated;
 // same operation order as oracle/geom_oracle.c)
-__device__ static int five_point_dev(const double *x1, const double *x2, double *E_out)
+// mx: this lane's 10x20 elimination matrix in LDS, element (i,j) at mx[(i*20+j)*64]
+// (lane-interleaved: conflict-free ds_read/write_b64, no scratch round trips)
+#define MX(i, j) mx[((i) * 20 + (j)) * 64]
+__device__ static int five_point_dev(const double *x1, const double *x2, double *E_out, double *mx)
 {
+#ifdef RPE_STAMPS
+    long long st_[8]; int sti_ = 0;
+#define STAMP() st_[sti_++] = clock64()
+#else
+#define STAMP()
+#endif
+    STAMP();
     double A[9][5];
     for (int k = 0; k < 5; ++k) {
         double a = x1[2 * k], b = x1[2 * k + 1], c = x2[2 * k], d = x2[2 * k + 1];
@@ -233,7 +243,7 @@ __device__ static int five_point_dev(const double *x1, const double *x2, double 
     }
     double El[9][4];
     for (int e = 0; e < 9; ++e) for (int m = 0; m < 4; ++m) El[e][m] = Eb[m][e];
-
+    STAMP();
     double EEt[3][3][10];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int q = 0; q < 10; ++q) EEt[i][j][q] = 0.;
     for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) {
@@ -244,37 +254,66 @@ __device__ static int five_point_dev(const double *x1, const double *x2, double 
     for (int q = 0; q < 10; ++q) htr[q] = 0.5 * ((EEt[0][0][q] + EEt[1][1][q]) + EEt[2][2][q]);
     for (int i = 0; i < 3; ++i) for (int q = 0; q < 10; ++q) EEt[i][i][q] -= htr[q];
 
-    double Mx[10][20];
-    for (int i = 0; i < 10; ++i) for (int j = 0; j < 20; ++j) Mx[i][j] = 0.;
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
-        for (int k = 0; k < 3; ++k) ql_acc(Mx[i * 3 + j], EEt[i][k], El[k * 3 + j], 1.);
+    // constraint rows are accumulated in registers/scratch one at a time, then stored to LDS
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        double row[20];
+        for (int q = 0; q < 20; ++q) row[q] = 0.;
+        for (int k = 0; k < 3; ++k) ql_acc(row, EEt[i][k], El[k * 3 + j], 1.);
+        for (int q = 0; q < 20; ++q) MX(i * 3 + j, q) = row[q];
+    }
     {
         double m0[10], m1[10], m2[10], neg[4];
         for (int q = 0; q < 10; ++q) { m0[q] = 0.; m1[q] = 0.; m2[q] = 0.; }
         ll_acc(m0, El[4], El[8]); for (int q = 0; q < 4; ++q) neg[q] = -El[5][q]; ll_acc(m0, neg, El[7]);
         ll_acc(m1, El[3], El[8]); ll_acc(m1, neg, El[6]);
         ll_acc(m2, El[3], El[7]); for (int q = 0; q < 4; ++q) neg[q] = -El[4][q]; ll_acc(m2, neg, El[6]);
-        ql_acc(Mx[9], m0, El[0], 1.);
-        ql_acc(Mx[9], m1, El[1], -1.);
-        ql_acc(Mx[9], m2, El[2], 1.);
+        double row[20];
+        for (int q = 0; q < 20; ++q) row[q] = 0.;
+        ql_acc(row, m0, El[0], 1.);
+        ql_acc(row, m1, El[1], -1.);
+        ql_acc(row, m2, El[2], 1.);
+        for (int q = 0; q < 20; ++q) MX(9, q) = row[q];
     }
+    STAMP();
     for (int c = 0; c < 10; ++c) {
-        int piv = c; double best = fabs(Mx[c][c]);
-        for (int r = c + 1; r < 10; ++r) { double a = fabs(Mx[r][c]); if (a > best) { best = a; piv = r; } }
+        double col[10];
+#pragma unroll
+        for (int r = 0; r < 10; ++r) col[r] = MX(r, c);          // 10 independent LDS reads in flight
+        int piv = c; double best = fabs(col[c]);
+        for (int r = c + 1; r < 10; ++r) { double a = fabs(col[r]); if (a > best) { best = a; piv = r; } }
         if (best == 0.) return 0;
-        if (piv != c) for (int j = 0; j < 20; ++j) { double t = Mx[c][j]; Mx[c][j] = Mx[piv][j]; Mx[piv][j] = t; }
-        double inv = 1. / Mx[c][c];
-        for (int j = c; j < 20; ++j) Mx[c][j] *= inv;
+        double prow[20], crow[20];
+#pragma unroll
+        for (int j = 0; j < 20; ++j) { prow[j] = MX(piv, j); crow[j] = MX(c, j); }
+        if (piv != c) {
+#pragma unroll
+            for (int j = 0; j < 20; ++j) MX(piv, j) = crow[j];
+            double t = col[c]; col[c] = col[piv]; col[piv] = t;
+        }
+        const double inv = 1. / prow[c];
+#pragma unroll
+        for (int j = 0; j < 20; ++j) { if (j >= c) prow[j] = prow[j] * inv; }
+#pragma unroll
+        for (int j = 0; j < 20; ++j) MX(c, j) = prow[j];
+#pragma unroll
         for (int r = 0; r < 10; ++r) {
             if (r == c) continue;
-            double f = Mx[r][c];
+            const double f = col[r];
             if (f == 0.) continue;
-            for (int j = c; j < 20; ++j) Mx[r][j] -= f * Mx[c][j];
+            double row[20];
+#pragma unroll
+            for (int j = 0; j < 20; ++j) row[j] = MX(r, j);
+#pragma unroll
+            for (int j = 0; j < 20; ++j) { if (j >= c) row[j] -= f * prow[j]; }
+#pragma unroll
+            for (int j = 0; j < 20; ++j) MX(r, j) = row[j];
         }
     }
+    STAMP();
     double Bx[3][4], By[3][4], B1[3][5];
     for (int i = 0; i < 3; ++i) {
-        const double *e = &Mx[4 + 2 * i][10], *f = &Mx[5 + 2 * i][10];
+        double e[10], f[10];
+        for (int q = 0; q < 10; ++q) { e[q] = MX(4 + 2 * i, 10 + q); f[q] = MX(5 + 2 * i, 10 + q); }
         Bx[i][3] = -f[0]; Bx[i][2] = e[0] - f[1]; Bx[i][1] = e[1] - f[2]; Bx[i][0] = e[2];
         By[i][3] = -f[3]; By[i][2] = e[3] - f[4]; By[i][1] = e[4] - f[5]; By[i][0] = e[5];
         B1[i][4] = -f[6]; B1[i][3] = e[6] - f[7]; B1[i][2] = e[7] - f[8]; B1[i][1] = e[8] - f[9]; B1[i][0] = e[9];
@@ -292,7 +331,9 @@ __device__ static int five_point_dev(const double *x1, const double *x2, double 
     int n = 10;
     for (; n > 1; --n) if (fabs(c10[n]) > DBL_EPSILON) break;
     double roots[10];
+    STAMP();
     int nroots = (n == 10) ? poly_real_roots10(c10, roots) : poly_real_roots_generic(c10, n, roots);
+    STAMP();
     int count = 0;
     for (int ri = 0; ri < nroots && count < 10; ++ri) {
         double z = roots[ri];
@@ -326,6 +367,11 @@ __device__ static int five_point_dev(const double *x1, const double *x2, double 
         for (int e = 0; e < 9; ++e) E_out[count * 9 + e] = Ev[e] / nrm;
         ++count;
     }
+    STAMP();
+#ifdef RPE_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("[stamps] null %lld build %lld gj %lld poly %lld roots %lld back %lld (nroots %d)\n", st_[1]-st_[0], st_[2]-st_[1], st_[3]-st_[2], st_[4]-st_[3], st_[5]-st_[4], st_[6]-st_[5], nroots);
+#endif
     return count;
 }
 
@@ -360,9 +406,13 @@ __global__ __launch_bounds__(64) void ransac_solve_kernel(const double2 *__restr
                                                            const RpeRansacState *__restrict__ st,
                                                            const unsigned short *__restrict__ subsets,
                                                            double *__restrict__ models, int *__restrict__ nmodels,
-                                                           int max_matches, int max_iters)
+                                                           int max_matches, int max_iters, int n_pairs)
 {
-    const int pair = blockIdx.x, lane = threadIdx.x;
+    // one wave = (64 / RPE_RANSAC_CHUNK) pairs x RPE_RANSAC_CHUNK consecutive iterations
+    __shared__ double s_mx[200 * 64];
+    const int sub = threadIdx.x / RPE_RANSAC_CHUNK, lane = threadIdx.x % RPE_RANSAC_CHUNK;
+    const int pair = blockIdx.x * (64 / RPE_RANSAC_CHUNK) + sub;
+    if (pair >= n_pairs) return;
     const RpeRansacState s = st[pair];
     if (s.done) return;
     const int it = s.next_iter + lane;
@@ -378,7 +428,7 @@ __global__ __launch_bounds__(64) void ransac_solve_kernel(const double2 *__restr
             x1[2 * k] = a.x; x1[2 * k + 1] = a.y; x2[2 * k] = b.x; x2[2 * k + 1] = b.y;
         }
         double E[90];
-        nm = five_point_dev(x1, x2, E);
+        nm = five_point_dev(x1, x2, E, s_mx + threadIdx.x);
         double *dst = models + slot * (RPE_MAX_MODELS * 9);
         for (int e = 0; e < nm * 9; ++e) dst[e] = E[e];
     }
@@ -525,8 +575,9 @@ void rpe_launch_ransac(rpe_handle *h, int B, bool want_mask)
     const int nchunks = (it + RPE_RANSAC_CHUNK - 1) / RPE_RANSAC_CHUNK;
     const size_t lds = sizeof(double2) * 2 * (size_t)mm;
     for (int c = 0; c < nchunks; ++c) {
-        hipLaunchKernelGGL(ransac_solve_kernel, dim3(B), dim3(64), 0, h->stream,
-                           n1, n2, h->d_rstate, h->d_subsets, h->d_models, h->d_nmodels, mm, it);
+        const int ppw = 64 / RPE_RANSAC_CHUNK;
+        hipLaunchKernelGGL(ransac_solve_kernel, dim3((B + ppw - 1) / ppw), dim3(64), 0, h->stream,
+                           n1, n2, h->d_rstate, h->d_subsets, h->d_models, h->d_nmodels, mm, it, B);
         hipLaunchKernelGGL(ransac_score_kernel, dim3(B), dim3(256), lds, h->stream,
                            n1, n2, h->d_rstate, h->d_models, h->d_nmodels, h->d_K, h->d_nit_denom, h->d_nit_round,
                            h->nit_num, h->cfg.ransac_threshold, h->d_E, h->d_found, mm);

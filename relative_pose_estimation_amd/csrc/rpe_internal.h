@@ -10,7 +10,7 @@
 #define RPE_NLEVELS RPE_ORB_LEVELS
 #define RPE_EDGE 31            // ORB edgeThreshold (cv2 default; pose_estimator.py:85-91 leaves it)
 #define RPE_HALF_PATCH 15      // patchSize 31
-#define RPE_RANSAC_CHUNK 64    // RANSAC iterations evaluated per launch group
+#define RPE_RANSAC_CHUNK 64    // RANSAC iterations evaluated per launch group (one solver wave per pair)
 #define RPE_MAX_MODELS 10
 
 // ---- HBM layout of one image's pyramid-shaped buffers ---------------------
