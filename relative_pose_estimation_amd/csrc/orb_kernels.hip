@@ -564,43 +564,120 @@ __device__ __forceinline__ void det_sincos(double x, double &sn, double &cs)
     }
 }
 
-// orb.cpp ICAngles: one wave per keypoint, lanes stride over the 749 disc pixels,
-// integer moments reduced with wave shuffles.
-__global__ __launch_bounds__(256) void ic_angle_kernel(const uint8_t *__restrict__ pyr, const unsigned *__restrict__ kp_xy,
-                                                        const int *__restrict__ kp_count, float *__restrict__ kp_angle,
-                                                        float2 *__restrict__ kp_cs, RpeDeviceLayout lay)
+// ------------------------------------------------- orientation + descriptor
+// Fused per-keypoint kernel (replaces the separate ICAngles, whole-pyramid GaussianBlur
+// and rBRIEF launches of the first version): one wave per keypoint, 4 keypoints per
+// workgroup.  The 45 x 48-byte raw patch around the keypoint is staged in LDS once and
+// feeds (1) the intensity-centroid moments over the radius-15 disc -> fastAtan2 angle,
+// (2) the horizontal pass of the fixed-point 7x7 Gaussian on the rows the descriptor can
+// touch, (3) the vertical pass evaluated only at the 512 steered sampling points.
+// Integer results are identical to blurring the whole level (the patch never reaches
+// the image border: keypoints are >= 31 px inside, the footprint is 22 px).
+#define KP_R 22
+#define KP_ROWS 45
+#define KP_RAW_DW 12                 // 48 bytes per raw row
+#define KP_H_DW 20                   // 40 u16 per horizontally blurred row
+__global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__restrict__ pyr, const unsigned *__restrict__ kp_xy,
+                                                               const float2 *__restrict__ kp_pt, const int *__restrict__ kp_count,
+                                                               float *__restrict__ kp_angle, uint8_t *__restrict__ desc,
+                                                               RpeDeviceLayout lay)
 {
-    const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), img = blockIdx.y;
-    if (k >= kp_count[img]) return;
-    unsigned p = kp_xy[(long long)img * lay.kcap + k];
+    __shared__ unsigned s_raw[4][KP_ROWS * KP_RAW_DW];
+    __shared__ unsigned s_hb[4][KP_ROWS * KP_H_DW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int k = blockIdx.x * 4 + wv, img = blockIdx.y;
+    const bool active = k < kp_count[img];
+    const long long g = (long long)img * lay.kcap + (active ? k : 0);
+    const unsigned p = kp_xy[g];
     const int x0 = p & 0xFFF, y0 = (p >> 12) & 0xFFF, l = p >> 24;
     const RpeLevel &L = lay.lv[l];
-    const uint8_t *c = pyr + (long long)img * lay.stride + L.off + (long long)y0 * L.pitch + x0;
-    int m10 = 0, m01 = 0;
-    const int nd = c_ndisc;
-    for (int i = lane; i < nd; i += 64) {
-        int u = c_disc[2 * i], v = c_disc[2 * i + 1];
-        int val = c[v * L.pitch + u];
-        m10 += u * val; m01 += v * val;
+    const int pitch = L.pitch;
+    const int xal = (x0 - KP_R) & ~3, off0 = (x0 - KP_R) - xal;     // off0 in 0..3
+    unsigned *raw = s_raw[wv], *hb = s_hb[wv];
+    if (active) {
+        const uint8_t *src = pyr + (long long)img * lay.stride + L.off + (long long)(y0 - KP_R) * pitch + xal;
+        for (int i = lane; i < KP_ROWS * KP_RAW_DW; i += 64) {
+            int r = i / KP_RAW_DW, c = i - r * KP_RAW_DW;
+            raw[i] = *(const unsigned *)(src + (long long)r * pitch + 4 * c);
+        }
     }
+    __syncthreads();
+    float a = 1.f, b = 0.f;
+    if (active) {
+        // ---- orb.cpp ICAngles: integer moments over the disc, reduced with wave shuffles
+        const uint8_t *rb = (const uint8_t *)raw + KP_R * (KP_RAW_DW * 4) + off0 + KP_R;   // centre pixel
+        int m10 = 0, m01 = 0;
+        const int nd = c_ndisc;
+        for (int i = lane; i < nd; i += 64) {
+            int u = c_disc[2 * i], v = c_disc[2 * i + 1];
+            int val = rb[v * (KP_RAW_DW * 4) + u];
+            m10 += u * val; m01 += v * val;
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
-    if (lane == 0) {
+        for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
         const float angle = fast_atan2_deg((float)m01, (float)m10);
-        kp_angle[(long long)img * lay.kcap + k] = angle;
-        // steering terms of computeOrbDescriptors, once per keypoint: a = cos, b = sin (f32)
+        if (lane == 0) kp_angle[g] = angle;
         const float ang = angle * (float)(3.141592653589793238462643383279502884 / 180.0);
         double sn, cs;
         det_sincos((double)ang, sn, cs);
-        kp_cs[(long long)img * lay.kcap + k] = make_float2((float)cs, (float)sn);
+        a = (float)cs; b = (float)sn;
+        // ---- horizontal pass: hbuf column j <-> x = x0 - 19 + j (40 per row; the descriptor
+        // reaches |dx| <= 18), 4 outputs per work item.  Output j of group gq needs raw bytes
+        // bo + j .. bo + j + 6 with bo = off0 + 4*gq (>= 0).
+        for (int i = lane; i < KP_ROWS * 10; i += 64) {
+            const int r = i / 10, gq = i - r * 10;
+            const int bo = off0 + 4 * gq, d0 = bo >> 2, sh = bo & 3;
+            const unsigned *rw = raw + r * KP_RAW_DW;
+            const unsigned w0 = rw[d0], w1 = rw[d0 + 1], w2 = rw[min(d0 + 2, KP_RAW_DW - 1)], w3 = rw[min(d0 + 3, KP_RAW_DW - 1)];
+            const unsigned q0 = __builtin_amdgcn_alignbyte(w1, w0, sh), q1 = __builtin_amdgcn_alignbyte(w2, w1, sh),
+                           q2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
+            unsigned px[12];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { px[t] = (q0 >> (8 * t)) & 255; px[4 + t] = (q1 >> (8 * t)) & 255; px[8 + t] = (q2 >> (8 * t)) & 255; }
+            unsigned o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = 18u * px[j] + 34u * px[j + 1] + 48u * px[j + 2] + 56u * px[j + 3] + 48u * px[j + 4] + 34u * px[j + 5] + 18u * px[j + 6];
+            hb[r * KP_H_DW + 2 * gq] = o[0] | (o[1] << 16);
+            hb[r * KP_H_DW + 2 * gq + 1] = o[2] | (o[3] << 16);
+        }
     }
+    __syncthreads();
+    if (!active) return;
+    // ---- orb.cpp computeOrbDescriptors: lane = 4 consecutive bit tests, vertical pass at the samples
+    const unsigned short *hs = (const unsigned short *)hb;
+    const float2 pt = kp_pt[g];
+    const float sc = 1.f / L.scale;
+    const int cx = __float2int_rn(pt.x * sc), cy = __float2int_rn(pt.y * sc);
+    const int dxo = cx - x0 + 19, dyo = cy - y0 + KP_R - 3;       // (cx,cy) == (x0,y0) in practice
+    unsigned nib = 0;
+#pragma unroll
+    for (int bit = 0; bit < 4; ++bit) {
+        const signed char *pp = c_pattern + 4 * (lane * 4 + bit);
+        float p0 = (float)pp[0], p1 = (float)pp[1], p2 = (float)pp[2], p3 = (float)pp[3];
+        float fx0 = p0 * a - p1 * b, fy0 = p0 * b + p1 * a;
+        float fx1 = p2 * a - p3 * b, fy1 = p2 * b + p3 * a;
+        int t01[2];
+        const int ixs[2] = {__float2int_rn(fx0), __float2int_rn(fx1)}, iys[2] = {__float2int_rn(fy0), __float2int_rn(fy1)};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const unsigned short *col = hs + (iys[e] + dyo) * (KP_H_DW * 2) + ixs[e] + dxo;
+            unsigned s = 18u * col[0] + 34u * col[KP_H_DW * 2] + 48u * col[2 * KP_H_DW * 2] + 56u * col[3 * KP_H_DW * 2] +
+                         48u * col[4 * KP_H_DW * 2] + 34u * col[5 * KP_H_DW * 2] + 18u * col[6 * KP_H_DW * 2];
+            t01[e] = (int)((s + 32768u) >> 16);
+        }
+        nib |= (unsigned)(t01[0] < t01[1]) << bit;
+    }
+    // 8 nibbles -> one dword (lanes 8m .. 8m+7), written by lane 8m
+    unsigned v = nib << (4 * (lane & 7));
+    v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 4);
+    if ((lane & 7) == 0) *(unsigned *)(desc + g * 32 + (lane >> 3) * 4) = v;
 }
 
 void rpe_launch_angle(rpe_handle *h, int n_img)
 {
-    hipLaunchKernelGGL(ic_angle_kernel, dim3((h->lay.kcap + 3) / 4, n_img), dim3(256), 0, h->stream,
-                       h->d_pyr, h->d_kp_xy, h->d_kp_count, h->d_kp_angle, h->d_kp_cs, h->lay);
+    hipLaunchKernelGGL(orient_describe_kernel, dim3((h->lay.kcap + 3) / 4, n_img), dim3(256), 0, h->stream,
+                       h->d_pyr, h->d_kp_xy, h->d_kp_pt, h->d_kp_count, h->d_kp_angle, h->d_desc, h->lay);
 }
 
 // ------------------------------------------------------------------- blur
@@ -681,41 +758,4 @@ void rpe_launch_blur(rpe_handle *h, int n_img)
 }
 
 // --------------------------------------------------------------- describe
-// orb.cpp computeOrbDescriptors (WTA_K = 2): 32 lanes per keypoint, lane = byte index.
-__global__ __launch_bounds__(256) void describe_kernel(const uint8_t *__restrict__ blur, const unsigned *__restrict__ kp_xy,
-                                                        const float2 *__restrict__ kp_pt, const float2 *__restrict__ kp_cs,
-                                                        const int *__restrict__ kp_count, uint8_t *__restrict__ desc,
-                                                        RpeDeviceLayout lay)
-{
-    const int byte = threadIdx.x & 31;
-    const int k = blockIdx.x * 8 + (threadIdx.x >> 5), img = blockIdx.y;
-    if (k >= kp_count[img]) return;
-    const long long g = (long long)img * lay.kcap + k;
-    const int l = kp_xy[g] >> 24;
-    const RpeLevel &L = lay.lv[l];
-    const float2 pt = kp_pt[g];
-    const float sc = 1.f / L.scale;
-    const float2 csn = kp_cs[g];
-    const float a = csn.x, b = csn.y;
-    const int cx = __float2int_rn(pt.x * sc), cy = __float2int_rn(pt.y * sc);
-    const int pitch = L.pitch;
-    const uint8_t *center = blur + (long long)img * lay.stride + L.off + (long long)cy * pitch + cx;
-    int val = 0;
-#pragma unroll
-    for (int bit = 0; bit < 8; ++bit) {
-        const signed char *p = c_pattern + 4 * (byte * 8 + bit);
-        float p0 = (float)p[0], p1 = (float)p[1], p2 = (float)p[2], p3 = (float)p[3];
-        float x0 = p0 * a - p1 * b, y0 = p0 * b + p1 * a;
-        float x1 = p2 * a - p3 * b, y1 = p2 * b + p3 * a;
-        int t0 = center[__float2int_rn(y0) * pitch + __float2int_rn(x0)];
-        int t1 = center[__float2int_rn(y1) * pitch + __float2int_rn(x1)];
-        val |= (t0 < t1) << bit;
-    }
-    desc[g * 32 + byte] = (uint8_t)val;
-}
-
-void rpe_launch_describe(rpe_handle *h, int n_img)
-{
-    hipLaunchKernelGGL(describe_kernel, dim3((h->lay.kcap + 7) / 8, n_img), dim3(256), 0, h->stream,
-                       h->d_bufA, h->d_kp_xy, h->d_kp_pt, h->d_kp_cs, h->d_kp_count, h->d_desc, h->lay);
-}
+void rpe_launch_describe(rpe_handle *h, int n_img) { (void)h; (void)n_img; }   // fused into orient_describe_kernel

@@ -385,7 +385,7 @@ static int load_level0_fast(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_
     return RPE_OK;
 }
 
-static int run_orb(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, int nb)
+static int run_orb(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, int nb, bool debug_blur = false)
 {
     const int n = na + nb;
     MARK(h, RPE_STAGE_PYRAMID);
@@ -398,7 +398,7 @@ static int run_orb(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na
     MARK(h, RPE_STAGE_HARRIS);    rpe_launch_harris(h, n);
     MARK(h, RPE_STAGE_KEYPOINTS); rpe_launch_keypoints(h, n);
     MARK(h, RPE_STAGE_ANGLE);     rpe_launch_angle(h, n);
-    MARK(h, RPE_STAGE_BLUR);      rpe_launch_blur(h, n);
+    MARK(h, RPE_STAGE_BLUR);      if (debug_blur) rpe_launch_blur(h, n);   // whole-level blur only for rpe_orb_debug_fetch
     MARK(h, RPE_STAGE_DESCRIBE);  rpe_launch_describe(h, n);
     MARK(h, RPE_STAGE_MATCH);
     HIPCHK(h, hipGetLastError());
@@ -482,7 +482,7 @@ extern "C" int rpe_orb_detect_and_compute(rpe_handle *h, const uint8_t *h_imgs, 
     const int na = n_images < h->cfg.max_batch ? n_images : h->cfg.max_batch, nb = n_images - na;
     HIPCHK(h, hipMemcpyAsync(h->d_stage1, h_imgs, img * na, hipMemcpyHostToDevice, h->stream));
     if (nb) HIPCHK(h, hipMemcpyAsync(h->d_stage2, h_imgs + img * na, img * nb, hipMemcpyHostToDevice, h->stream));
-    int rc = run_orb(h, h->d_stage1, h->d_stage2, na, nb);
+    int rc = run_orb(h, h->d_stage1, h->d_stage2, na, nb, true);
     if (rc) return rc;
     const int kcap = h->lay.kcap;
     std::vector<unsigned> xy((size_t)n_images * kcap);
