@@ -52,6 +52,22 @@ def stage_bytes(stage, W, H, pyr_px, nkp, mm):
     raise KeyError(stage)
 
 
+STAGE_KERNEL = {"fast": "fast_nms_kernel", "angle": "orient_describe_kernel", "select": "select_candidates_kernel",
+                "harris": "harris_kernel", "keypoints": "select_keypoints_kernel", "match": "match_hamming_kernel",
+                "pose": "recover_pose_kernel"}
+
+
+def pmc_traffic(stage, pairs_per_launch, W, H, nfeatures):
+    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes),
+    or None when no profile exists for this kernel / workload."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if stage not in STAGE_KERNEL or not os.path.exists(path) or (W, H, nfeatures, pairs_per_launch) != (640, 480, 1000, 1024):
+        return None
+    k = json.load(open(path))["kernels"].get(STAGE_KERNEL[stage])
+    return k["hbm_bytes_per_launch"] if k else None
+
+
 def cpu_baseline(i1, i2, K, nfeatures, max_matches, sample):
     """The oracle (a scalar C port of the reference's cv2 calls) timed on this host's
     cores on a bounded sample of the same workload."""
@@ -173,15 +189,17 @@ def main():
     R, t, inl, nm, st = local
     ok = st == 0
     errs = np.array([geometry.rotation_error(R[i], Rgt[i]) for i in range(B) if ok[i]])
-    stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
+    # per-LAUNCH averages: every step launches each kernel group once per stream on B/S pairs
+    stage_ms = {k: v / (args.steps * S) for k, v in stage_acc.items()}
+    Bl = B // S if B % S == 0 else B / S          # pairs per launch
     pyr_px = eng.lib.rpe_orb_pyramid_pixels(eng.h)
 
     if rank == 0:
         dom = max(stage_ms, key=stage_ms.get)
-        dom_bytes = stage_bytes(dom, W, H, pyr_px, args.nfeatures, args.max_matches) * B
+        dom_bytes = stage_bytes(dom, W, H, pyr_px, args.nfeatures, args.max_matches) * Bl
         achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
         # the matcher is the stage north_star attaches a roofline target to: always report it too
-        m_bytes = stage_bytes("match", W, H, pyr_px, args.nfeatures, args.max_matches) * B
+        m_bytes = stage_bytes("match", W, H, pyr_px, args.nfeatures, args.max_matches) * Bl
         m_achieved = m_bytes / (stage_ms["match"] * 1e-3) / 1e9
         out = {
             "metric": "image-pairs/s end-to-end (640x480 pairs), median rotation-angle error alongside",
@@ -198,12 +216,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{B} {W}x{H} pairs per GPU, ORB({args.nfeatures}kp)+BF-Hamming crossCheck top-{args.max_matches}"
                                    "+5pt-RANSAC(0.999,1px)+recoverPose (BASELINE configs[1])",
-                       "pairs_per_gpu": B, "global_pairs": world * B, "sharding": f"pairs x{world}, RCCL all-gather of 128-B pose records"},
+                       "pairs_per_gpu": B, "global_pairs": world * B, "streams_per_gpu": S, "pairs_per_launch": Bl, "sharding": f"pairs x{world}, RCCL all-gather of 128-B pose records"},
             "median_rotation_error_deg": float(np.median(errs)) if len(errs) else None,
             "pairs_ok": int(ok.sum()),
-            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "stage_ms_per_launch": {k: round(v, 4) for k, v in stage_ms.items()},
+            "roofline": {"kernel": STAGE_KERNEL.get(dom, dom), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, Bl, W, H, args.nfeatures),
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": stage_ms[dom],
                          "matcher": {"achieved": m_achieved, "frac": m_achieved / HBM_PEAK_GBS,
                                      "algorithmic_bytes_per_launch": m_bytes, "avg_launch_ms": stage_ms["match"]}},

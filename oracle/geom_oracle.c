@@ -106,11 +106,18 @@ static void ql_acc(double *c, const double *a, const double *b, double s)
 }
 
 /* ------------------------------------------------- real roots of a poly */
+/* Polynomial evaluation by a fixed Estrin scheme for degree <= 10 (coefficients above
+ * n are zero).  Chosen over Horner because its dependency depth is 7 instead of 20
+ * operations -- the HIP root finder is latency bound -- and restated identically here. */
 static double horner(const double *c, int n, double x)
 {
-    double acc = c[n];
-    for (int i = n - 1; i >= 0; --i) acc = acc * x + c[i];
-    return acc;
+    double cc[11];
+    for (int i = 0; i < 11; ++i) cc[i] = i <= n ? c[i] : 0.;
+    const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+    const double a0 = cc[0] + cc[1] * x, a1 = cc[2] + cc[3] * x, a2 = cc[4] + cc[5] * x;
+    const double a3 = cc[6] + cc[7] * x, a4 = cc[8] + cc[9] * x, a5 = cc[10];
+    const double b0 = a0 + a1 * x2, b1 = a2 + a3 * x2, b2 = a4 + a5 * x2;
+    return (b0 + b1 * x4) + b2 * x8;
 }
 
 /* Safeguarded Newton (bisection fallback) on a bracket [a,b] with a sign change of

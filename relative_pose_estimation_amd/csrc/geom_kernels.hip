@@ -34,11 +34,17 @@ __device__ static void ql_acc(double *c, const double *a, const double *b, doubl
     for (int i = 0; i < 10; ++i) for (int j = 0; j < 4; ++j) c[QL2C[i][j]] += s * (a[i] * b[j]);
 }
 
+// Fixed Estrin scheme for degree <= 10 (dependency depth 7 instead of Horner's 20; the
+// root finder is latency bound).  Identical arithmetic to oracle/geom_oracle.c.
 __device__ static double horner(const double *c, int n, double x)
 {
-    double acc = c[n];
-    for (int i = n - 1; i >= 0; --i) acc = acc * x + c[i];
-    return acc;
+    double cc[11];
+    for (int i = 0; i < 11; ++i) cc[i] = i <= n ? c[i] : 0.;
+    const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+    const double a0 = cc[0] + cc[1] * x, a1 = cc[2] + cc[3] * x, a2 = cc[4] + cc[5] * x;
+    const double a3 = cc[6] + cc[7] * x, a4 = cc[8] + cc[9] * x, a5 = cc[10];
+    const double b0 = a0 + a1 * x2, b1 = a2 + a3 * x2, b2 = a4 + a5 * x2;
+    return (b0 + b1 * x4) + b2 * x8;
 }
 
 // Safeguarded Newton on a bracket with a sign change (same code path as the oracle).
@@ -100,13 +106,23 @@ __device__ static int poly_real_roots_generic(const double *c, int n, double *ro
 
 // ---- degree-10 fast path: the polynomial of each chain level lives in registers
 // (static indexing); arithmetic identical to the generic path.
+// static-degree Estrin: terms whose coefficients are structurally zero (index > K) are
+// omitted; they would only add exact zeros, so the value equals horner(c, K, x) bit for bit.
 template <int K>
 __device__ __forceinline__ double horner_s(const double (&c)[11], double x)
 {
-    double acc = c[K];
-#pragma unroll
-    for (int i = K - 1; i >= 0; --i) acc = acc * x + c[i];
-    return acc;
+    const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+    auto A = [&](int i) -> double {           // a_i = c[2i] + c[2i+1] x
+        if (2 * i + 1 <= K) return c[2 * i] + c[2 * i + 1] * x;
+        return (2 * i <= K) ? c[2 * i] : 0.;
+    };
+    double b0, b1 = 0., b2 = 0.;
+    b0 = (2 <= K) ? A(0) + A(1) * x2 : A(0);
+    if (4 <= K) b1 = (6 <= K) ? A(2) + A(3) * x2 : A(2);
+    if (8 <= K) b2 = (10 <= K) ? A(4) + c[10] * x2 : A(4);
+    double r = (4 <= K) ? b0 + b1 * x4 : b0;
+    if (8 <= K) r = r + b2 * x8;
+    return r;
 }
 
 template <int K>

@@ -31,6 +31,16 @@ void rpe_orb_upload_disc(const signed char *disc, int n)
     hipMemcpyToSymbol(HIP_SYMBOL(c_ndisc), &n, sizeof(int));
 }
 
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an
+// XCD and its L2), so workgroup b takes tile (b % 8) * ceil(n/8) + b / 8: every XCD walks one
+// contiguous run of the raster-ordered tile list and neighbouring tiles (shared halo rows and
+// shared 128-B lines) hit the same L2.  Only speed depends on this, never correctness.
+__device__ __forceinline__ int xcd_tile(int b, int n)
+{
+    const int per = (n + 7) >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+
 // ---------------------------------------------------------------- pyramid
 // Workgroup = 64x64 destination tile of level l.  The source footprint in level l-1
 // (<= 74 rows x 80 bytes, bounds derived arithmetically so the loads do not depend on
@@ -44,8 +54,11 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
     const RpeLevel &S = lay.lv[l - 1];
     const RpeLevel &D = lay.lv[l];
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
-    uint8_t *base = pyr + (long long)blockIdx.z * lay.stride;
+    const int tcols = (D.pitch + 63) >> 6, trows = (D.h + 63) >> 6;
+    const int ti = xcd_tile(blockIdx.x, tcols * trows);
+    if (ti >= tcols * trows) return;
+    const int x0 = (ti % tcols) * 64, y0 = (ti / tcols) * 64;
+    uint8_t *base = pyr + (long long)blockIdx.y * lay.stride;
     const uint8_t *src = base + S.off;
     const int *xo = coef + D.coef_off, *xa = xo + D.w, *yo = xa + D.w, *ya = yo + D.h;
     // conservative footprint: floor(scale*x0) <= xo[x0] (scale >= 1), checked on the host
@@ -95,8 +108,8 @@ void rpe_launch_pyramid(rpe_handle *h, int n_img)
 {
     for (int l = 1; l < RPE_NLEVELS; ++l) {
         const RpeLevel &D = h->lay.lv[l];
-        dim3 grid((D.pitch + 63) / 64, (D.h + 63) / 64, n_img);
-        hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, h->stream, h->d_pyr, h->lay, h->d_coef, l);
+        const int nt = ((D.pitch + 63) / 64) * ((D.h + 63) / 64);
+        hipLaunchKernelGGL(pyr_resize_kernel, dim3((nt + 7) / 8 * 8, n_img), dim3(256), 0, h->stream, h->d_pyr, h->lay, h->d_coef, l);
     }
 }
 
@@ -123,7 +136,7 @@ static constexpr int CIRC_DY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0
 #define FS_ROWS 66          // score rows / columns region (y0-1 .. y0+64)
 __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ nms,
                                                         unsigned *__restrict__ hist, RpeDeviceLayout lay,
-                                                        const RpeTile *__restrict__ tiles)
+                                                        const RpeTile *__restrict__ tiles, int ntiles)
 {
     __shared__ unsigned s_in[72 * 18];              // pixels  y0-4 .. y0+67, x0-4 .. x0+67
     __shared__ unsigned s_sc[FS_ROWS * 18];         // scores  y0-1 .. y0+64, x0-4 .. x0+67
@@ -132,7 +145,9 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
     __shared__ unsigned s_hist[256];
     __shared__ int s_ncand;
     const int tid = threadIdx.x, lane = tid & 63;
-    const RpeTile t = tiles[blockIdx.x];
+    const int ti = xcd_tile(blockIdx.x, ntiles);
+    if (ti >= ntiles) return;
+    const RpeTile t = tiles[ti];
     const RpeLevel &L = lay.lv[t.level];
     const int w = L.w, hgt = L.h, pitch = L.pitch, thr = lay.fast_thr;
     const int x0 = t.tx, y0 = t.ty;
@@ -282,8 +297,8 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
 void rpe_launch_fast(rpe_handle *h, int n_img)
 {
     hipMemsetAsync(h->d_hist, 0, sizeof(unsigned) * 256 * RPE_NLEVELS * (size_t)n_img, h->stream);
-    hipLaunchKernelGGL(fast_nms_kernel, dim3(h->n_tiles_full, n_img), dim3(256), 0, h->stream,
-                       h->d_pyr, h->d_bufB, h->d_hist, h->lay, h->d_tiles_full);
+    hipLaunchKernelGGL(fast_nms_kernel, dim3((h->n_tiles_full + 7) / 8 * 8, n_img), dim3(256), 0, h->stream,
+                       h->d_pyr, h->d_bufB, h->d_hist, h->lay, h->d_tiles_full, h->n_tiles_full);
 }
 
 void rpe_launch_nms(rpe_handle *h, int n_img) { (void)h; (void)n_img; }   // fused into fast_nms_kernel
