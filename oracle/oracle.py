@@ -213,3 +213,26 @@ def estimate_pose_batch(imgs1, imgs2, K, nfeatures=4000, max_matches=500, nthrea
     out = np.zeros(B, POSE_DTYPE)
     lib().orc_estimate_pose_batch(_p(imgs1), _p(imgs2), B, W, H, _p(K), nfeatures, max_matches, _p(out), nthreads)
     return out
+
+
+SIFT_KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4")])
+
+
+def sift_detect_and_compute(img, nfeatures=0, seed_cap=32768, cap=None):
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    cap = cap or (nfeatures + 64 if nfeatures > 0 else 4 * seed_cap)
+    kps = np.zeros(cap, SIFT_KP_DTYPE); desc = np.zeros((cap, 128), np.float32)
+    n = lib().orc_sift_detect_and_compute(_p(img), W, H, int(nfeatures), int(seed_cap), _p(kps), _p(desc), cap)
+    return kps[:n].copy(), desc[:n].copy()
+
+
+def sift_gauss_pyramid(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    dims = np.zeros(64, np.int32)
+    lib().orc_sift_gauss_pyramid.restype = C.c_int64
+    n = lib().orc_sift_gauss_pyramid(_p(img), W, H, None, _p(dims))
+    out = np.zeros(n, np.float32)
+    lib().orc_sift_gauss_pyramid(_p(img), W, H, _p(out), _p(dims))
+    return out, dims
