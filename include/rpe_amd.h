@@ -87,6 +87,15 @@ typedef struct rpe_keypoint {
     int32_t lx, ly;      /* integer coordinates inside the pyramid level */
 } rpe_keypoint;
 
+/* SIFT keypoint record (cv2.KeyPoint fields), stage API */
+typedef struct rpe_sift_keypoint {
+    float x, y;          /* kp.pt in input-image coordinates */
+    float size;          /* kp.size */
+    float angle;         /* kp.angle, degrees */
+    float response;      /* kp.response = |contrast| */
+    int32_t octave;      /* kp.octave, OpenCV's packed (octave | layer<<8 | offset<<16) form */
+} rpe_sift_keypoint;
+
 /* ------------------------------------------------------------ lifecycle */
 void rpe_default_config(rpe_config *cfg);
 /* replaces PoseEstimator.__init__ / _create_feature_extractor / _create_matcher
@@ -146,6 +155,21 @@ int64_t rpe_orb_pyramid_pixels(const rpe_handle *h);
 int rpe_match_hamming(rpe_handle *h, const uint8_t *h_desc1, const int32_t *n1,
                       const uint8_t *h_desc2, const int32_t *n2, int B,
                       int32_t *qidx, int32_t *tidx, int32_t *dist, int32_t *n_matches);
+
+/* replaces cv2.SIFT_create().detectAndCompute(image, None) (pose_estimator.py:93-94, :108); the
+ * handle must have been created with feature_method = RPE_FEATURE_SIFT, norm_type = RPE_NORM_L2.
+ * cfg.nfeatures is the keypoint cap (SIFT_create(nfeatures); BASELINE config 3 uses 2048 -- the
+ * reference itself passes no cap).  kps[n_images*cap], desc[n_images*cap*128] f32, counts[n_images]. */
+int rpe_sift_detect_and_compute(rpe_handle *h, const uint8_t *h_imgs, int n_images,
+                                rpe_sift_keypoint *kps, float *desc, int32_t *counts);
+/* Gaussian pyramid of image `index` of the last SIFT run (octave-major, 6 levels per octave, tight
+ * rows); returns the float count (out may be NULL to query it) */
+int64_t rpe_sift_debug_gauss(rpe_handle *h, int index, float *out);
+
+/* replaces BFMatcher(NORM_L2, crossCheck=True).match + sorted + truncate (pose_estimator.py:127-131,
+ * :144-151) for SIFT descriptors (integer-valued f32, B*cap*128 each).  dist: f32 L2 distances. */
+int rpe_match_l2(rpe_handle *h, const float *h_desc1, const int32_t *n1, const float *h_desc2,
+                 const int32_t *n2, int B, int32_t *qidx, int32_t *tidx, float *dist, int32_t *n_matches);
 
 /* replaces cv2.findEssentialMat(pts1, pts2, K, RANSAC, prob, threshold)
  * (pose_estimator.py:522-527).  pts: B*max_matches*2 f32, m[B] counts.

@@ -25,6 +25,7 @@ EXPORTS = [
     "rpe_fetch_results", "rpe_fetch_matched_points", "rpe_orb_detect_and_compute", "rpe_orb_debug_fetch",
     "rpe_orb_pyramid_pixels", "rpe_match_hamming", "rpe_find_essential", "rpe_recover_pose",
     "rpe_set_profiling", "rpe_get_stage_ms", "rpe_stage_name",
+    "rpe_sift_detect_and_compute", "rpe_sift_debug_gauss", "rpe_match_l2",
 ]
 
 
@@ -37,6 +38,9 @@ class Config(C.Structure):
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("lx", "<i4"), ("ly", "<i4")])
+
+SIFT_KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                          ("octave", "<i4")])
 
 _lib = None
 
@@ -86,6 +90,11 @@ def load():
     lib.rpe_set_profiling.argtypes = [vp, C.c_int]; lib.rpe_set_profiling.restype = C.c_int
     lib.rpe_get_stage_ms.argtypes = [vp, vp]; lib.rpe_get_stage_ms.restype = C.c_int
     lib.rpe_stage_name.argtypes = [C.c_int]; lib.rpe_stage_name.restype = C.c_char_p
+    lib.rpe_sift_detect_and_compute.argtypes = [vp, vp, C.c_int, vp, vp, i32p]
+    lib.rpe_sift_detect_and_compute.restype = C.c_int
+    lib.rpe_sift_debug_gauss.argtypes = [vp, C.c_int, vp]; lib.rpe_sift_debug_gauss.restype = C.c_int64
+    lib.rpe_match_l2.argtypes = [vp, vp, i32p, vp, i32p, C.c_int, i32p, i32p, vp, i32p]
+    lib.rpe_match_l2.restype = C.c_int
     _lib = lib
     return lib
 
@@ -197,6 +206,32 @@ class Engine:
         out = np.zeros(self.lib.rpe_orb_pyramid_pixels(self.h), np.uint8)
         self._chk(self.lib.rpe_orb_debug_fetch(self.h, index, which, _p(out)))
         return out
+
+    def sift_detect_and_compute(self, imgs):
+        imgs = np.ascontiguousarray(imgs, np.uint8)
+        n = imgs.shape[0]
+        kps = np.zeros((n, self.kcap), SIFT_KP_DTYPE); desc = np.zeros((n, self.kcap, 128), np.float32)
+        cnt = np.zeros(n, np.int32)
+        self._chk(self.lib.rpe_sift_detect_and_compute(self.h, _p(imgs), n, _p(kps), _p(desc), _p(cnt)))
+        return kps, desc, cnt
+
+    def sift_debug_gauss(self, index):
+        n = self.lib.rpe_sift_debug_gauss(self.h, index, None)
+        out = np.zeros(n, np.float32)
+        self.lib.rpe_sift_debug_gauss(self.h, index, _p(out))
+        return out
+
+    def match_l2(self, desc1, n1, desc2, n2):
+        B = len(n1)
+        d1 = np.zeros((B, self.kcap, 128), np.float32); d2 = np.zeros_like(d1)
+        for i in range(B):
+            d1[i, :n1[i]] = desc1[i][:n1[i]]; d2[i, :n2[i]] = desc2[i][:n2[i]]
+        n1 = np.ascontiguousarray(n1, np.int32); n2 = np.ascontiguousarray(n2, np.int32)
+        mm = self.max_matches
+        q = np.zeros((B, mm), np.int32); t = np.zeros((B, mm), np.int32); d = np.zeros((B, mm), np.float32)
+        nm = np.zeros(B, np.int32)
+        self._chk(self.lib.rpe_match_l2(self.h, _p(d1), _p(n1), _p(d2), _p(n2), B, _p(q), _p(t), _p(d), _p(nm)))
+        return q, t, d, nm
 
     def match_hamming(self, desc1, n1, desc2, n2):
         B = len(n1)

@@ -14,6 +14,7 @@
 //   describe : steered BRIEF, 32 lanes per keypoint (one descriptor byte per lane)
 // Everything is integer or mirrored-order f32, so results equal the CPU oracle bit for bit.
 #include "rpe_internal.h"
+#include "rpe_devmath.h"
 
 #define TW 64
 #define TH 64
@@ -533,50 +534,6 @@ void rpe_launch_keypoints(rpe_handle *h, int n_img)
     hipLaunchKernelGGL(select_keypoints_kernel, dim3(n_img), dim3(256), 0, h->stream,
                        h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_pt,
                        h->d_kp_count, h->lay);
-}
-
-// ------------------------------------------------------------------ angle
-__device__ __forceinline__ float fast_atan2_deg(float y, float x)
-{
-    const float scale = (float)(180.0 / 3.141592653589793238462643383279502884);
-    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
-    const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
-    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
-    if (ax >= ay) {
-        c = ay / (ax + (float)2.2204460492503131e-16);
-        c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    } else {
-        c = ax / (ay + (float)2.2204460492503131e-16);
-        c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    }
-    if (x < 0) a = 180.f - a;
-    if (y < 0) a = 360.f - a;
-    return a;
-}
-
-// deterministic sin/cos (fdlibm kernel polynomials); identical op order to the oracle
-__device__ __forceinline__ void det_sincos(double x, double &sn, double &cs)
-{
-    const double PIO2_HI = 1.57079632673412561417e+00, PIO2_LO = 6.07710050650619224932e-11;
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
-                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
-                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    int k = (int)(x * 0.63661977236758134308 + 0.5);
-    double r = (x - (double)k * PIO2_HI) - (double)k * PIO2_LO;
-    double z = r * r;
-    double ps = S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))));
-    double pc = C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6))));
-    double s = r + (r * z) * ps;
-    double c = (1.0 - 0.5 * z) + (z * z) * pc;
-    switch (k & 3) {
-    case 0: sn = s;  cs = c;  break;
-    case 1: sn = c;  cs = -s; break;
-    case 2: sn = -s; cs = -c; break;
-    default: sn = -c; cs = s; break;
-    }
 }
 
 // ------------------------------------------------- orientation + descriptor

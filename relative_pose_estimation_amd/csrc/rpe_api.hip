@@ -238,10 +238,11 @@ static int alloc_workspace(rpe_handle *h)
 {
     const RpeDeviceLayout &L = h->lay;
     const size_t NI = (size_t)h->n_img_cap, B = (size_t)h->cfg.max_batch, mm = (size_t)h->cfg.max_matches;
-    DM(h, h->d_pyr, NI * L.stride); DM(h, h->d_bufA, NI * L.stride); DM(h, h->d_bufB, NI * L.stride);
-    HIPCHK(h, hipMemset(h->d_bufA, 0, NI * L.stride));
-    HIPCHK(h, hipMemset(h->d_bufB, 0, NI * L.stride));
-    HIPCHK(h, hipMemset(h->d_pyr, 0, NI * L.stride));
+    const size_t NIo = h->cfg.feature_method == RPE_FEATURE_SIFT ? 1 : NI;   // ORB pyramid buffers are unused by SIFT handles
+    DM(h, h->d_pyr, NIo * L.stride); DM(h, h->d_bufA, NIo * L.stride); DM(h, h->d_bufB, NIo * L.stride);
+    HIPCHK(h, hipMemset(h->d_bufA, 0, NIo * L.stride));
+    HIPCHK(h, hipMemset(h->d_bufB, 0, NIo * L.stride));
+    HIPCHK(h, hipMemset(h->d_pyr, 0, NIo * L.stride));
     const size_t img = (size_t)h->cfg.width * h->cfg.height;
     DM(h, h->d_stage1, B * img); DM(h, h->d_stage2, B * img);
     DM(h, h->d_hist, NI * RPE_NLEVELS * 256);
@@ -249,7 +250,7 @@ static int alloc_workspace(rpe_handle *h)
     DM(h, h->d_cand_count, NI * RPE_NLEVELS);
     DM(h, h->d_kp_xy, NI * L.kcap); DM(h, h->d_kp_resp, NI * L.kcap); DM(h, h->d_kp_angle, NI * L.kcap);
     DM(h, h->d_kp_pt, NI * L.kcap); DM(h, h->d_kp_cs, NI * L.kcap); DM(h, h->d_kp_count, NI);
-    DM(h, h->d_desc, NI * L.kcap * 32);
+    DM(h, h->d_desc, NI * L.kcap * h->desc_bytes);
     HIPCHK(h, hipMemset(h->d_kp_pt, 0, NI * L.kcap * sizeof(float2)));
     HIPCHK(h, hipMemset(h->d_kp_count, 0, NI * sizeof(int)));
     DM(h, h->d_m_q, B * mm); DM(h, h->d_m_t, B * mm); DM(h, h->d_m_d, B * mm); DM(h, h->d_m_n, B);
@@ -270,8 +271,13 @@ extern "C" int rpe_create(const rpe_config *cfg, rpe_handle **out)
     if (!cfg || !out) { g_create_err = "null argument"; return RPE_ERR_INVALID; }
     *out = nullptr;
     if (cfg->abi_version != RPE_ABI_VERSION) { g_create_err = "ABI version mismatch"; return RPE_ERR_INVALID; }
-    if (cfg->feature_method != RPE_FEATURE_ORB || cfg->norm_type != RPE_NORM_HAMMING) {
-        g_create_err = "only ORB + Hamming is implemented on the HIP path"; return RPE_ERR_INVALID;
+    const bool is_sift = cfg->feature_method == RPE_FEATURE_SIFT;
+    if (!((cfg->feature_method == RPE_FEATURE_ORB && cfg->norm_type == RPE_NORM_HAMMING) ||
+          (is_sift && cfg->norm_type == RPE_NORM_L2))) {
+        g_create_err = "supported combinations: ORB + Hamming, SIFT + L2"; return RPE_ERR_INVALID;
+    }
+    if (is_sift && (cfg->nfeatures > 4032 || cfg->width > 4000 || cfg->height > 4000)) {
+        g_create_err = "SIFT: nfeatures (keypoint cap) must be <= 4032 and the image <= 4000 px"; return RPE_ERR_INVALID;
     }
     if (cfg->width < 96 || cfg->height < 96 || cfg->width > 4095 || cfg->height > 4095 || cfg->max_batch < 1 ||
         cfg->nfeatures < 1 || cfg->nfeatures > 8000 || cfg->max_matches < 5 || cfg->max_matches > 2048 ||
@@ -286,6 +292,7 @@ extern "C" int rpe_create(const rpe_config *cfg, rpe_handle **out)
     rpe_handle *h = new rpe_handle();
     h->cfg = *cfg;
     h->n_img_cap = 2 * cfg->max_batch;
+    h->desc_bytes = is_sift ? 128 : 32;
     int rc = RPE_OK;
     do {
         if (hipSetDevice(cfg->device) != hipSuccess) { h->err = "hipSetDevice failed"; rc = RPE_ERR_HIP; break; }
@@ -293,6 +300,7 @@ extern "C" int rpe_create(const rpe_config *cfg, rpe_handle **out)
         build_layout(h);
         if ((rc = build_tables(h)) != RPE_OK) break;
         if ((rc = alloc_workspace(h)) != RPE_OK) break;
+        if (is_sift && (rc = rpe_sift_create(h)) != RPE_OK) break;
         for (int i = 0; i <= RPE_STAGE_COUNT; ++i)
             if (hipEventCreate(&h->ev[i]) != hipSuccess) { h->err = "hipEventCreate failed"; rc = RPE_ERR_HIP; break; }
     } while (0);
@@ -306,6 +314,7 @@ extern "C" void rpe_destroy(rpe_handle *h)
     if (!h) return;
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    rpe_sift_destroy(h);
     void *ptrs[] = {h->d_tiles_full, h->d_tiles_fast, h->d_coef, h->d_pyr, h->d_bufA, h->d_bufB, h->d_stage1, h->d_stage2,
                     h->d_hist, h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_angle,
                     h->d_kp_pt, h->d_kp_cs, h->d_kp_count, h->d_desc, h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2,
@@ -418,8 +427,15 @@ extern "C" int rpe_enqueue_batch_device(rpe_handle *h, const uint8_t *d_imgs1, c
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int rc = set_K(h, K);
     if (rc) return rc;
-    if ((rc = run_orb(h, d_imgs1, d_imgs2, B, B)) != RPE_OK) return rc;
-    rpe_launch_match(h, B);
+    if (h->cfg.feature_method == RPE_FEATURE_SIFT) {
+        MARK(h, RPE_STAGE_PYRAMID);
+        if ((rc = rpe_sift_run(h, d_imgs1, d_imgs2, B, B)) != RPE_OK) return rc;
+        for (int s = RPE_STAGE_FAST; s <= RPE_STAGE_MATCH; ++s) MARK(h, s);
+        rpe_launch_match_l2(h, B);
+    } else {
+        if ((rc = run_orb(h, d_imgs1, d_imgs2, B, B)) != RPE_OK) return rc;
+        rpe_launch_match(h, B);
+    }
     MARK(h, RPE_STAGE_RANSAC);
     rpe_launch_ransac(h, B, false);
     MARK(h, RPE_STAGE_POSE);
@@ -476,6 +492,7 @@ extern "C" int rpe_orb_detect_and_compute(rpe_handle *h, const uint8_t *h_imgs, 
                                           rpe_keypoint *kps, uint8_t *desc, int32_t *counts)
 {
     if (!h || !h_imgs || n_images < 1) return RPE_ERR_INVALID;
+    if (h->cfg.feature_method != RPE_FEATURE_ORB) { h->err = "handle was not created for ORB"; return RPE_ERR_INVALID; }
     if (n_images > h->n_img_cap) { h->err = "n_images exceeds 2*max_batch"; return RPE_ERR_CAPACITY; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const size_t img = (size_t)h->cfg.width * h->cfg.height;
@@ -664,5 +681,83 @@ extern "C" int rpe_debug_calibrate(rpe_handle *h, long long *bytes_out)
                        h->d_pyr, v.pitch, v.h, (size_t)h->lay.stride, (unsigned *)h->d_hist);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (bytes_out) { bytes_out[0] = (long long)bytes; bytes_out[1] = (long long)bytes; bytes_out[2] = (long long)(v.pitch / 64) * (v.h / 64) * 64 * 64 * h->n_img_cap; }
+    return RPE_OK;
+}
+
+
+// ------------------------------------------------------------------ SIFT stage API
+extern "C" int rpe_sift_detect_and_compute(rpe_handle *h, const uint8_t *h_imgs, int n_images,
+                                           rpe_sift_keypoint *kps, float *desc, int32_t *counts)
+{
+    if (!h || !h_imgs || n_images < 1) return RPE_ERR_INVALID;
+    if (h->cfg.feature_method != RPE_FEATURE_SIFT) { h->err = "handle was not created for SIFT"; return RPE_ERR_INVALID; }
+    if (n_images > h->n_img_cap) { h->err = "n_images exceeds 2*max_batch"; return RPE_ERR_CAPACITY; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t img = (size_t)h->cfg.width * h->cfg.height;
+    const int na = n_images < h->cfg.max_batch ? n_images : h->cfg.max_batch, nb = n_images - na;
+    HIPCHK(h, hipMemcpyAsync(h->d_stage1, h_imgs, img * na, hipMemcpyHostToDevice, h->stream));
+    if (nb) HIPCHK(h, hipMemcpyAsync(h->d_stage2, h_imgs + img * na, img * nb, hipMemcpyHostToDevice, h->stream));
+    int rc = rpe_sift_run(h, h->d_stage1, h->d_stage2, na, nb);
+    if (rc) return rc;
+    const int kcap = h->lay.kcap;
+    std::vector<float> fin((size_t)n_images * kcap * 6);
+    std::vector<int> cnt(n_images);
+    std::vector<uint8_t> d8(desc ? (size_t)n_images * kcap * 128 : 0);
+    if ((rc = rpe_sift_fetch(h, n_images, fin.data(), cnt.data())) != RPE_OK) return rc;
+    if (desc) {
+        HIPCHK(h, hipMemcpy(d8.data(), h->d_desc, d8.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < d8.size(); ++i) desc[i] = (float)d8[i];       // cv2 returns SIFT descriptors as f32
+    }
+    for (int i = 0; i < n_images; ++i) {
+        if (counts) counts[i] = cnt[i];
+        if (!kps) continue;
+        for (int k = 0; k < cnt[i]; ++k) {
+            const float *f = &fin[((size_t)i * kcap + k) * 6];
+            rpe_sift_keypoint &o = kps[(size_t)i * kcap + k];
+            int oct; memcpy(&oct, &f[5], 4);
+            o.x = f[0] * 0.5f; o.y = f[1] * 0.5f; o.size = f[2] * 0.5f; o.angle = f[3]; o.response = f[4];
+            o.octave = (oct & ~255) | ((oct - 1) & 255);                          // firstOctave = -1 (sift.dispatch.cpp)
+        }
+    }
+    return RPE_OK;
+}
+
+extern "C" int64_t rpe_sift_debug_gauss(rpe_handle *h, int index, float *out)
+{
+    if (!h || !h->sift) return 0;
+    if (out && rpe_sift_fetch_gauss(h, index, out) != RPE_OK) return -1;
+    return rpe_sift_gauss_floats(h);
+}
+
+extern "C" int rpe_match_l2(rpe_handle *h, const float *h_desc1, const int32_t *n1, const float *h_desc2, const int32_t *n2, int B,
+                            int32_t *qidx, int32_t *tidx, float *dist, int32_t *n_matches)
+{
+    if (!h || !h_desc1 || !h_desc2 || !n1 || !n2 || B < 1) return RPE_ERR_INVALID;
+    if (h->cfg.norm_type != RPE_NORM_L2) { h->err = "handle was not created for NORM_L2"; return RPE_ERR_INVALID; }
+    if (B > h->cfg.max_batch) { h->err = "batch exceeds max_batch"; return RPE_ERR_CAPACITY; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t per = (size_t)h->lay.kcap * 128, mm = h->cfg.max_matches;
+    std::vector<uint8_t> u(2 * per * B, 0);
+    for (int s = 0; s < 2; ++s) {
+        const float *src = s ? h_desc2 : h_desc1; const int32_t *cn = s ? n2 : n1;
+        for (int i = 0; i < B; ++i) {
+            if (cn[i] < 0 || cn[i] > h->lay.kcap) { h->err = "descriptor count exceeds keypoint capacity"; return RPE_ERR_INVALID; }
+            for (size_t e = 0; e < (size_t)cn[i] * 128; ++e) {
+                float v = src[(size_t)i * per + e];
+                if (!(v >= 0.f && v <= 255.f) || v != (float)(int)v) { h->err = "NORM_L2 path expects SIFT descriptors (integer-valued 0..255)"; return RPE_ERR_INVALID; }
+                u[(size_t)s * per * B + (size_t)i * per + e] = (uint8_t)v;
+            }
+        }
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_desc, u.data(), u.size(), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_kp_count, n1, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_kp_count + B, n2, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+    rpe_launch_match_l2(h, B);
+    HIPCHK(h, hipGetLastError());
+    if (qidx) HIPCHK(h, hipMemcpyAsync(qidx, h->d_m_q, sizeof(int) * mm * B, hipMemcpyDeviceToHost, h->stream));
+    if (tidx) HIPCHK(h, hipMemcpyAsync(tidx, h->d_m_t, sizeof(int) * mm * B, hipMemcpyDeviceToHost, h->stream));
+    if (dist) HIPCHK(h, hipMemcpyAsync(dist, h->d_m_d, sizeof(float) * mm * B, hipMemcpyDeviceToHost, h->stream));
+    if (n_matches) HIPCHK(h, hipMemcpyAsync(n_matches, h->d_m_n, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return RPE_OK;
 }

@@ -52,8 +52,12 @@ struct RpeRansacState {
     double E[9];      // best model so far
 };
 
+struct RpeSiftState;
+
 struct rpe_handle {
     rpe_config cfg;
+    RpeSiftState *sift = nullptr;             // SIFT workspace (feature_method == RPE_FEATURE_SIFT)
+    int desc_bytes = 32;                      // 32 (rBRIEF) or 128 (SIFT, stored as u8)
     std::string err;
     hipStream_t stream = nullptr;
     RpeDeviceLayout lay;
@@ -113,5 +117,12 @@ void rpe_launch_angle(rpe_handle *h, int n_img);
 void rpe_launch_blur(rpe_handle *h, int n_img);
 void rpe_launch_describe(rpe_handle *h, int n_img);
 void rpe_launch_match(rpe_handle *h, int B);
+void rpe_launch_match_l2(rpe_handle *h, int B);
+int rpe_sift_create(rpe_handle *h);
+void rpe_sift_destroy(rpe_handle *h);
+int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, int nb);
+int rpe_sift_fetch(rpe_handle *h, int n_images, float *fin_host, int *counts);
+int rpe_sift_fetch_gauss(rpe_handle *h, int index, float *out);
+long long rpe_sift_gauss_floats(rpe_handle *h);
 void rpe_launch_ransac(rpe_handle *h, int B, bool want_mask);
 void rpe_launch_pose(rpe_handle *h, int B, bool set_status);

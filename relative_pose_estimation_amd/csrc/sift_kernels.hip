@@ -1,0 +1,767 @@
+// sift_kernels.hip -- SIFT detectAndCompute on gfx950 (BASELINE config 3).
+//
+// Replaces cv2.SIFT_create().detectAndCompute(image, None) (reference
+// src/core/pose_estimator.py:93-94, :108).  Algorithm = OpenCV 4.x sift.dispatch.cpp /
+// sift.simd.hpp as restated in oracle/sift_oracle.c; every f32 operation keeps the oracle's
+// order (contraction off, deterministic exp/sincos, fixed partial-sum trees), so results
+// compare bit for bit.  Kernel groups (all images of the batch per launch):
+//   upsample  : u8 -> f32, 2x INTER_LINEAR
+//   blur      : separable Gaussian (row pass through an LDS segment, column pass), reflect-101
+//   halve     : INTER_NEAREST octave decimation
+//   dog       : difference of neighbouring Gaussian levels
+//   extrema   : 26-neighbour test; two passes (count, emit) over row bands give a raster-
+//               ordered seed list without a serial scan of the image
+//   refine    : one wave per seed: adjustLocalExtrema on lane 0, orientation histogram on all
+//               64 lanes (8 LDS rounds x 8 lanes keep the per-slot summation order), peaks
+//   sort      : bitonic sort of the raw keypoints by KeyPoint_LessThan (one workgroup / image)
+//   finalize  : duplicate removal, retainBest(nfeatures) by radix select, ordered compaction
+//   describe  : one wave per keypoint, 4x4x8 trilinear histogram in 8 interleaved partials
+#include "rpe_internal.h"
+#include "rpe_devmath.h"
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+#define S_NOL 3
+#define S_NG 6
+#define S_ND 5
+#define S_BORDER 5
+#define S_BINS 36
+
+__constant__ float c_skern[6][32];     // [0] initial blur, [1..5] incremental octave blurs
+__constant__ int c_sks[6];
+
+struct SiftBand { short o, l; int r0, r1; };
+
+struct SiftDev {                        // passed by value to kernels
+    int noct;
+    int w[12], h[12];
+    long long goff[12], doff[12];       // float offsets inside the per-image gaussian / DoG buffers
+    long long gstride, dstride, tstride; // floats per image
+    int seed_cap, raw_cap, kcap, nfeatures, nbands;
+};
+
+struct RpeSiftState {
+    SiftDev dv;
+    float *d_gauss = nullptr, *d_dog = nullptr, *d_tmp = nullptr;
+    SiftBand *d_bands = nullptr;
+    int *d_band_cnt = nullptr, *d_band_off = nullptr;     // [img][nbands]
+    unsigned *d_seeds = nullptr; int *d_nseeds = nullptr; // [img][seed_cap], [img]
+    float *d_raw = nullptr;                                // [img][raw_cap][6]: x y size angle response octave(bits)
+    int *d_nraw = nullptr, *d_overflow = nullptr;
+    unsigned long long *d_k0 = nullptr, *d_k1 = nullptr; unsigned *d_sidx = nullptr; // sort keys [img][raw_pad]
+    int raw_pad = 0;
+    float *d_fin = nullptr;                                // [img][kcap][6] un-halved keypoints in sorted order
+};
+
+// ------------------------------------------------------------------ image ops
+__global__ __launch_bounds__(256) void sift_upsample_kernel(const uint8_t *__restrict__ img, int W, int H, size_t img_stride,
+                                                             float *__restrict__ dst, long long dstride)
+{
+    const int bw = 2 * W;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= bw) return;
+    const uint8_t *s = img + (size_t)blockIdx.z * img_stride;
+    float fy = (y + 0.5f) * 0.5f - 0.5f; int sy = (int)floorf(fy); fy -= sy;
+    if (sy < 0) { sy = 0; fy = 0.f; }
+    int sy1 = sy + 1 < H ? sy + 1 : H - 1;
+    if (sy >= H - 1) { sy = H - 1; sy1 = H - 1; fy = 0.f; }
+    float fx = (x + 0.5f) * 0.5f - 0.5f; int sx = (int)floorf(fx); fx -= sx;
+    if (sx < 0) { sx = 0; fx = 0.f; }
+    int sx1 = sx + 1 < W ? sx + 1 : W - 1;
+    if (sx >= W - 1) { sx = W - 1; sx1 = W - 1; fx = 0.f; }
+    float h0 = (float)s[(size_t)sy * W + sx] * (1.f - fx) + (float)s[(size_t)sy * W + sx1] * fx;
+    float h1 = (float)s[(size_t)sy1 * W + sx] * (1.f - fx) + (float)s[(size_t)sy1 * W + sx1] * fx;
+    dst[(long long)blockIdx.z * dstride + (size_t)y * bw + x] = h0 * (1.f - fy) + h1 * fy;
+}
+
+__device__ __forceinline__ int s_refl(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) { if (p < 0) p = -p; if (p >= n) p = 2 * n - 2 - p; }
+    return p;
+}
+
+// row pass: one workgroup = 256 consecutive pixels of one row, taps staged in an LDS segment
+__global__ __launch_bounds__(256) void sift_blur_row_kernel(const float *__restrict__ src, long long sstride, float *__restrict__ dst,
+                                                             long long dstride, int w, int h, int kid)
+{
+    __shared__ float seg[256 + 32];
+    const int ks = c_sks[kid], r = ks >> 1;
+    const int x0 = blockIdx.x * 256, y = blockIdx.y;
+    const float *s = src + (long long)blockIdx.z * sstride + (size_t)y * w;
+    for (int i = threadIdx.x; i < 256 + 2 * r; i += 256) seg[i] = s[s_refl(x0 + i - r, w)];
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    if (x >= w) return;
+    float acc = 0.f;
+    for (int i = 0; i < ks; ++i) acc += c_skern[kid][i] * seg[threadIdx.x + i];
+    dst[(long long)blockIdx.z * dstride + (size_t)y * w + x] = acc;
+}
+
+__global__ __launch_bounds__(256) void sift_blur_col_kernel(const float *__restrict__ src, long long sstride, float *__restrict__ dst,
+                                                             long long dstride, int w, int h, int kid)
+{
+    const int ks = c_sks[kid], r = ks >> 1;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const float *s = src + (long long)blockIdx.z * sstride;
+    float acc = 0.f;
+    for (int i = 0; i < ks; ++i) acc += c_skern[kid][i] * s[(size_t)s_refl(y + i - r, h) * w + x];
+    dst[(long long)blockIdx.z * dstride + (size_t)y * w + x] = acc;
+}
+
+__global__ __launch_bounds__(256) void sift_halve_kernel(const float *__restrict__ src, float *__restrict__ dst, long long stride,
+                                                          int sw, int w, int h)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const long long b = (long long)blockIdx.z * stride;
+    dst[b + (size_t)y * w + x] = src[b + (size_t)(2 * y) * sw + 2 * x];
+}
+
+__global__ __launch_bounds__(256) void sift_dog_kernel(const float *__restrict__ g, long long gstride, float *__restrict__ d,
+                                                        long long dstride, long long n /* w*h */)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *gg = g + (long long)blockIdx.z * gstride;
+    float *dd = d + (long long)blockIdx.z * dstride;
+    float prev = gg[i];
+#pragma unroll
+    for (int l = 0; l < S_ND; ++l) { float nx = gg[(l + 1) * n + i]; dd[l * n + i] = nx - prev; prev = nx; }
+}
+
+// ------------------------------------------------------------------ extrema
+__device__ __forceinline__ int s_block_excl_scan(int v, int *s_wave, int &total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(inc, o); if (lane >= o) inc += n; }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { int s = s_wave[k]; if (k < wv) base += s; }
+    total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__device__ __forceinline__ bool sift_is_extremum(const float *d, long long n, int w, int l, int r, int c)
+{
+    const float val = d[l * n + (size_t)r * w + c];
+    if (!(fabsf(val) > 1.f)) return false;
+    bool ismax = val > 0, ismin = val < 0;
+    for (int dl = -1; dl <= 1; ++dl)
+        for (int dr = -1; dr <= 1; ++dr) {
+            const float *p = d + (l + dl) * n + (size_t)(r + dr) * w + c;
+            float a = p[-1], b = p[0], e = p[1];
+            ismax = ismax && !(a > val) && !(b > val) && !(e > val);
+            ismin = ismin && !(a < val) && !(b < val) && !(e < val);
+        }
+    return ismax || ismin;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void sift_extrema_kernel(const float *__restrict__ dog, SiftDev dv, const SiftBand *__restrict__ bands,
+                                                            int *__restrict__ band_cnt, const int *__restrict__ band_off,
+                                                            unsigned *__restrict__ seeds)
+{
+    __shared__ int s_wave[5];
+    const SiftBand bd = bands[blockIdx.x];
+    const int img = blockIdx.y, o = bd.o, w = dv.w[o];
+    const long long n = (long long)w * dv.h[o];
+    const float *d = dog + (long long)img * dv.dstride + dv.doff[o];
+    const int cols = w - 2 * S_BORDER, npx = (bd.r1 - bd.r0) * cols;
+    int base = EMIT ? band_off[img * dv.nbands + blockIdx.x] : 0;
+    int count = 0;
+    for (int p0 = 0; p0 < npx; p0 += 256) {
+        const int p = p0 + threadIdx.x;
+        bool hit = false; int r = 0, c = 0;
+        if (p < npx) { r = bd.r0 + p / cols; c = S_BORDER + p % cols; hit = sift_is_extremum(d, n, w, bd.l, r, c); }
+        int total;
+        const int ex = s_block_excl_scan(hit ? 1 : 0, s_wave, total);
+        if (EMIT && hit) {
+            const int idx = base + ex;
+            if (idx < dv.seed_cap) seeds[(long long)img * dv.seed_cap + idx] = ((unsigned)o << 28) | ((unsigned)bd.l << 26) | ((unsigned)r << 13) | (unsigned)c;
+        }
+        base += total; count += total;
+    }
+    if (!EMIT && threadIdx.x == 0) band_cnt[img * dv.nbands + blockIdx.x] = count;
+}
+
+__global__ void sift_band_scan_kernel(const int *__restrict__ band_cnt, int *__restrict__ band_off, int *__restrict__ nseeds, SiftDev dv)
+{
+    const int img = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    int acc = 0;
+    for (int b = 0; b < dv.nbands; ++b) { band_off[img * dv.nbands + b] = acc; acc += band_cnt[img * dv.nbands + b]; }
+    nseeds[img] = acc < dv.seed_cap ? acc : dv.seed_cap;
+}
+
+// ------------------------------------------------------- refine + orientation
+struct DogCtx { const float *d; long long n; int w, h; };
+__device__ __forceinline__ float DOGV(const DogCtx &c, int l, int r, int x) { return c.d[l * c.n + (size_t)r * c.w + x]; }
+
+__device__ static bool sift_adjust(const DogCtx &c, int &layer, int &r, int &x, float &xi_, float &xr_, float &xc_, float &contr_)
+{
+    const float img_scale = 1.f / 255, deriv_scale = img_scale * 0.5f, second = img_scale, cross = img_scale * 0.25f;
+    float xi = 0, xr = 0, xc = 0;
+    int i = 0, l = layer, rr = r, cc = x;
+    for (; i < 5; ++i) {
+        float dD0 = (DOGV(c, l, rr, cc + 1) - DOGV(c, l, rr, cc - 1)) * deriv_scale;
+        float dD1 = (DOGV(c, l, rr + 1, cc) - DOGV(c, l, rr - 1, cc)) * deriv_scale;
+        float dD2 = (DOGV(c, l + 1, rr, cc) - DOGV(c, l - 1, rr, cc)) * deriv_scale;
+        float v2 = DOGV(c, l, rr, cc) * 2;
+        float dxx = (DOGV(c, l, rr, cc + 1) + DOGV(c, l, rr, cc - 1) - v2) * second;
+        float dyy = (DOGV(c, l, rr + 1, cc) + DOGV(c, l, rr - 1, cc) - v2) * second;
+        float dss = (DOGV(c, l + 1, rr, cc) + DOGV(c, l - 1, rr, cc) - v2) * second;
+        float dxy = (DOGV(c, l, rr + 1, cc + 1) - DOGV(c, l, rr + 1, cc - 1) - DOGV(c, l, rr - 1, cc + 1) + DOGV(c, l, rr - 1, cc - 1)) * cross;
+        float dxs = (DOGV(c, l + 1, rr, cc + 1) - DOGV(c, l + 1, rr, cc - 1) - DOGV(c, l - 1, rr, cc + 1) + DOGV(c, l - 1, rr, cc - 1)) * cross;
+        float dys = (DOGV(c, l + 1, rr + 1, cc) - DOGV(c, l + 1, rr - 1, cc) - DOGV(c, l - 1, rr + 1, cc) + DOGV(c, l - 1, rr - 1, cc)) * cross;
+        float A[3][4] = {{dxx, dxy, dxs, dD0}, {dxy, dyy, dys, dD1}, {dxs, dys, dss, dD2}};
+        bool ok = true;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            int piv = p;
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) if (fabsf(A[q][p]) > fabsf(A[piv][p])) piv = q;
+            if (fabsf(A[piv][p]) < FLT_EPSILON) { ok = false; break; }
+            if (piv != p) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { float t = A[p][q]; A[p][q] = A[piv][q]; A[piv][q] = t; }
+            }
+            float d = -1.f / A[p][p];
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                float al = A[q][p] * d;
+#pragma unroll
+                for (int s = p + 1; s < 4; ++s) A[q][s] += al * A[p][s];
+            }
+        }
+        float X0 = 0, X1 = 0, X2 = 0;
+        if (ok) {
+            X2 = A[2][3] / A[2][2];
+            X1 = (A[1][3] - A[1][2] * X2) / A[1][1];
+            X0 = (A[0][3] - A[0][1] * X1 - A[0][2] * X2) / A[0][0];
+        }
+        xi = -X2; xr = -X1; xc = -X0;
+        if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
+        if (fabsf(xi) > (float)(INT_MAX / 3) || fabsf(xr) > (float)(INT_MAX / 3) || fabsf(xc) > (float)(INT_MAX / 3)) return false;
+        cc += __float2int_rn(xc); rr += __float2int_rn(xr); l += __float2int_rn(xi);
+        if (l < 1 || l > S_NOL || cc < S_BORDER || cc >= c.w - S_BORDER || rr < S_BORDER || rr >= c.h - S_BORDER) return false;
+    }
+    if (i >= 5) return false;
+    {
+        float dD0 = (DOGV(c, l, rr, cc + 1) - DOGV(c, l, rr, cc - 1)) * deriv_scale;
+        float dD1 = (DOGV(c, l, rr + 1, cc) - DOGV(c, l, rr - 1, cc)) * deriv_scale;
+        float dD2 = (DOGV(c, l + 1, rr, cc) - DOGV(c, l - 1, rr, cc)) * deriv_scale;
+        float t = (dD0 * xc + dD1 * xr) + dD2 * xi;
+        float contr = DOGV(c, l, rr, cc) * img_scale + t * 0.5f;
+        if (fabsf(contr) * S_NOL < 0.04f) return false;
+        float v2 = DOGV(c, l, rr, cc) * 2.f;
+        float dxx = (DOGV(c, l, rr, cc + 1) + DOGV(c, l, rr, cc - 1) - v2) * second;
+        float dyy = (DOGV(c, l, rr + 1, cc) + DOGV(c, l, rr - 1, cc) - v2) * second;
+        float dxy = (DOGV(c, l, rr + 1, cc + 1) - DOGV(c, l, rr + 1, cc - 1) - DOGV(c, l, rr - 1, cc + 1) + DOGV(c, l, rr - 1, cc - 1)) * cross;
+        float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
+        if (det <= 0 || tr * tr * 10.f >= (10.f + 1) * (10.f + 1) * det) return false;
+        contr_ = contr;
+    }
+    layer = l; r = rr; x = cc; xi_ = xi; xr_ = xr; xc_ = xc;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void sift_refine_kernel(const float *__restrict__ gauss, const float *__restrict__ dog, SiftDev dv,
+                                                           const unsigned *__restrict__ seeds, const int *__restrict__ nseeds,
+                                                           float *__restrict__ raw, int *__restrict__ nraw, int *__restrict__ overflow)
+{
+    __shared__ float s_part[4][S_BINS][8];
+    __shared__ float s_hist[4][S_BINS + 4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sidx = blockIdx.x * 4 + wv, img = blockIdx.y;
+    if (sidx >= nseeds[img]) return;                       // whole wave exits; no block-level barrier below
+    const unsigned sd = seeds[(long long)img * dv.seed_cap + sidx];
+    const int o = sd >> 28;
+    int l = (sd >> 26) & 3, r = (sd >> 13) & 0x1FFF, c = sd & 0x1FFF;
+    const int w = dv.w[o], h = dv.h[o];
+    const long long n = (long long)w * h;
+    DogCtx dc = {dog + (long long)img * dv.dstride + dv.doff[o], n, w, h};
+    float xi = 0, xr = 0, xc = 0, contr = 0;
+    int ok = 0;
+    if (lane == 0) ok = sift_adjust(dc, l, r, c, xi, xr, xc, contr) ? 1 : 0;
+    ok = __shfl(ok, 0);
+    if (!ok) return;
+    l = __shfl(l, 0); r = __shfl(r, 0); c = __shfl(c, 0);
+    xi = __shfl(xi, 0); xr = __shfl(xr, 0); xc = __shfl(xc, 0); contr = __shfl(contr, 0);
+    const float kx = ((float)c + xc) * (float)(1 << o), ky = ((float)r + xr) * (float)(1 << o);
+    const int koct = o + (l << 8) + (__double2int_rn(((double)xi + 0.5) * 255) << 16);
+    const float ksize = 1.6f * det_exp2f(((float)l + xi) / S_NOL) * (float)(1 << o) * 2;
+    const float kresp = fabsf(contr);
+    // ---- calcOrientationHist on gaussian level l of this octave
+    const float scl_octv = ksize * 0.5f / (float)(1 << o);
+    const int radius = __float2int_rn(4.5f * scl_octv);
+    const float sigma = 1.5f * scl_octv;
+    const float expf_scale = -1.f / (2.f * sigma * sigma);
+    const float *img_l = gauss + (long long)img * dv.gstride + dv.goff[o] + (long long)l * n;
+    volatile float (*part)[8] = s_part[wv];
+    for (int i = lane; i < S_BINS * 8; i += 64) ((volatile float *)part)[i] = 0.f;
+    const int side = 2 * radius + 1, nsamp = side * side;
+    for (int k0 = 0; k0 < nsamp; k0 += 64) {
+        const int k = k0 + lane;
+        bool valid = k < nsamp;
+        int bin = 0; float contrib = 0.f;
+        if (valid) {
+            const int i = k / side - radius, j = k % side - radius;
+            const int y = r + i, x = c + j;
+            valid = !(y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1);
+            if (valid) {
+                const float dx = img_l[(size_t)y * w + x + 1] - img_l[(size_t)y * w + x - 1];
+                const float dy = img_l[(size_t)(y - 1) * w + x] - img_l[(size_t)(y + 1) * w + x];
+                const float wgt = det_expf((float)(i * i + j * j) * expf_scale);
+                const float ori = fast_atan2_deg(dy, dx);
+                const float mag = sqrtf(dx * dx + dy * dy);
+                bin = __float2int_rn((S_BINS / 360.f) * ori);
+                if (bin >= S_BINS) bin -= S_BINS;
+                if (bin < 0) bin += S_BINS;
+                contrib = wgt * mag;
+            }
+        }
+        // 8 rounds of 8 lanes: slot (lane & 7) receives its samples in ascending k
+#pragma unroll
+        for (int rd = 0; rd < 8; ++rd) {
+            if ((lane >> 3) == rd && valid) part[bin][lane & 7] = part[bin][lane & 7] + contrib;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    volatile float *th = s_hist[wv] + 2;
+    if (lane < S_BINS) {
+        float p0 = part[lane][0], p1 = part[lane][1], p2 = part[lane][2], p3 = part[lane][3];
+        float p4 = part[lane][4], p5 = part[lane][5], p6 = part[lane][6], p7 = part[lane][7];
+        p0 = p0 + p4; p1 = p1 + p5; p2 = p2 + p6; p3 = p3 + p7;
+        p0 = p0 + p2; p1 = p1 + p3;
+        th[lane] = p0 + p1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { th[-1] = th[S_BINS - 1]; th[-2] = th[S_BINS - 2]; th[S_BINS] = th[0]; th[S_BINS + 1] = th[1]; }
+    __builtin_amdgcn_wave_barrier();
+    float hv = -1.f;
+    if (lane < S_BINS)
+        hv = (th[lane - 2] + th[lane + 2]) * (1.f / 16.f) + (th[lane - 1] + th[lane + 1]) * (4.f / 16.f) + th[lane] * (6.f / 16.f);
+    float omax = hv;
+#pragma unroll
+    for (int of = 32; of > 0; of >>= 1) omax = fmaxf(omax, __shfl_xor(omax, of));
+    const float mag_thr = omax * 0.8f;
+    const float hl = __shfl(hv, lane > 0 ? lane - 1 : S_BINS - 1), hr = __shfl(hv, lane < S_BINS - 1 ? lane + 1 : 0);
+    if (lane < S_BINS && hv > hl && hv > hr && hv >= mag_thr) {
+        float bin = (float)lane + 0.5f * (hl - hr) / (hl - 2 * hv + hr);
+        bin = bin < 0 ? S_BINS + bin : bin >= S_BINS ? bin - S_BINS : bin;
+        float angle = 360.f - (360.f / S_BINS) * bin;
+        if (fabsf(angle - 360.f) < FLT_EPSILON) angle = 0.f;
+        const int slot = atomicAdd(&nraw[img], 1);
+        if (slot < dv.raw_cap) {
+            float *q = raw + ((long long)img * dv.raw_cap + slot) * 6;
+            q[0] = kx; q[1] = ky; q[2] = ksize; q[3] = angle; q[4] = kresp; q[5] = __int_as_float(koct);
+        } else overflow[img] = 1;
+    }
+}
+
+// ------------------------------------------------------------------ sort
+// KeyPoint_LessThan as a 128-bit key: (x, y) ascending, size descending, angle ascending.
+// Exact duplicates (same seed end point) get identical keys and become neighbours.
+__global__ __launch_bounds__(1024) void sift_sort_kernel(const float *__restrict__ raw, const int *__restrict__ nraw, SiftDev dv, int pad,
+                                                          unsigned long long *__restrict__ k0, unsigned long long *__restrict__ k1,
+                                                          unsigned *__restrict__ sidx)
+{
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int n = min(nraw[img], dv.raw_cap);
+    int P = 64;
+    while (P < n) P <<= 1;
+    unsigned long long *a0 = k0 + (long long)img * pad, *a1 = k1 + (long long)img * pad;
+    unsigned *ix = sidx + (long long)img * pad;
+    for (int i = tid; i < P; i += 1024) {
+        unsigned long long u0 = ~0ull, u1 = ~0ull;
+        if (i < n) {
+            const float *q = raw + ((long long)img * dv.raw_cap + i) * 6;
+            u0 = ((unsigned long long)__float_as_uint(q[0]) << 32) | __float_as_uint(q[1]);     // x, y > 0: bit order = value order
+            u1 = ((unsigned long long)(~__float_as_uint(q[2])) << 32) | __float_as_uint(q[3]);
+        }
+        a0[i] = u0; a1[i] = u1; ix[i] = (unsigned)i;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += 1024) {
+                const int i = 2 * j * (t / j) + (t % j), ixj = i + j;
+                const bool asc = (i & k) == 0;
+                const unsigned long long x0 = a0[i], x1 = a1[i], y0 = a0[ixj], y1 = a1[ixj];
+                // the payload index breaks ties so the result does not depend on the append order
+                const unsigned xi = ix[i], yi = ix[ixj];
+                const bool gt = x0 > y0 || (x0 == y0 && (x1 > y1 || (x1 == y1 && xi > yi)));
+                if (gt == asc) { a0[i] = y0; a1[i] = y1; ix[i] = yi; a0[ixj] = x0; a1[ixj] = x1; ix[ixj] = xi; }
+            }
+            __syncthreads();
+        }
+}
+
+// ---------------------------------------------------------------- finalize
+__device__ __forceinline__ unsigned s_float_key(float f)
+{
+    unsigned u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void sift_finalize_kernel(const float *__restrict__ raw, const int *__restrict__ nraw, SiftDev dv, int pad,
+                                                             const unsigned long long *__restrict__ k0, const unsigned long long *__restrict__ k1,
+                                                             const unsigned *__restrict__ sidx, float *__restrict__ fin,
+                                                             float2 *__restrict__ kp_pt, int *__restrict__ kp_count)
+{
+    __shared__ unsigned s_hist[256];
+    __shared__ int s_wave[5];
+    __shared__ unsigned s_prefix;
+    __shared__ int s_kk, s_nuniq;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int n = min(nraw[img], dv.raw_cap);
+    const unsigned long long *a0 = k0 + (long long)img * pad, *a1 = k1 + (long long)img * pad;
+    const unsigned *ix = sidx + (long long)img * pad;
+    const float *rw = raw + (long long)img * dv.raw_cap * 6;
+    auto uniq = [&](int i) { return i == 0 || a0[i] != a0[i - 1] || a1[i] != a1[i - 1]; };
+    // count unique keypoints (removeDuplicatedSorted)
+    if (tid == 0) s_nuniq = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int i = tid; i < n; i += 256) cnt += uniq(i) ? 1 : 0;
+    atomicAdd(&s_nuniq, cnt);
+    __syncthreads();
+    const int nuniq = s_nuniq;
+    unsigned thr_key = 0;
+    if (dv.nfeatures > 0 && nuniq > dv.nfeatures) {       // retainBest: response >= the nfeatures-th best
+        unsigned prefix = 0, mask = 0;
+        if (tid == 0) s_kk = dv.nfeatures;
+        for (int pass = 3; pass >= 0; --pass) {
+            const int shift = 8 * pass;
+            s_hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += 256)
+                if (uniq(i)) {
+                    unsigned key = s_float_key(rw[(long long)ix[i] * 6 + 4]);
+                    if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255], 1u);
+                }
+            __syncthreads();
+            if (tid == 0) {
+                int kk = s_kk, acc = 0, bin = 0;
+                for (int b = 255; b >= 0; --b) { int c = (int)s_hist[b]; if (acc + c >= kk) { bin = b; break; } acc += c; }
+                s_kk = kk - acc;
+                s_prefix = prefix | ((unsigned)bin << shift);
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            mask |= 255u << shift;
+        }
+        thr_key = prefix;
+    }
+    int offset = 0;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + tid;
+        bool keep = false;
+        if (i < n && uniq(i)) keep = s_float_key(rw[(long long)ix[i] * 6 + 4]) >= thr_key;
+        int total;
+        const int ex = s_block_excl_scan(keep ? 1 : 0, s_wave, total);
+        if (keep) {
+            const int o = offset + ex;
+            if (o < dv.kcap) {
+                const float *q = rw + (long long)ix[i] * 6;
+                float *f = fin + ((long long)img * dv.kcap + o) * 6;
+                f[0] = q[0]; f[1] = q[1]; f[2] = q[2]; f[3] = q[3]; f[4] = q[4]; f[5] = q[5];
+                kp_pt[(long long)img * dv.kcap + o] = make_float2(q[0] * 0.5f, q[1] * 0.5f);   // firstOctave = -1
+            }
+        }
+        offset += total;
+    }
+    if (tid == 0) kp_count[img] = min(offset, dv.kcap);
+}
+
+// ---------------------------------------------------------------- descriptor
+__global__ __launch_bounds__(256) void sift_describe_kernel(const float *__restrict__ gauss, SiftDev dv, const float *__restrict__ fin,
+                                                             const int *__restrict__ kp_count, uint8_t *__restrict__ desc)
+{
+    __shared__ float s_part[4][360][8];
+    __shared__ float s_hist[4][360];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int kidx = blockIdx.x * 4 + wv, img = blockIdx.y;
+    if (kidx >= kp_count[img]) return;
+    const float *f = fin + ((long long)img * dv.kcap + kidx) * 6;
+    const int koct = __float_as_int(f[5]);
+    const int o = koct & 255, l = (koct >> 8) & 255;
+    const float scale = 1.f / (float)(1 << o);
+    const float size = f[2] * scale;
+    float angle = 360.f - f[3];
+    if (fabsf(angle - 360.f) < FLT_EPSILON) angle = 0.f;
+    const float ptx = f[0] * scale, pty = f[1] * scale, ori = angle, scl = size * 0.5f;
+    const int w = dv.w[o], h = dv.h[o];
+    const float *img_l = gauss + (long long)img * dv.gstride + dv.goff[o] + (long long)l * w * h;
+    const int d = 4, n = 8;
+    const int px = __float2int_rn(ptx), py = __float2int_rn(pty);
+    double sn, cs;
+    det_sincos((double)(ori * (float)(3.141592653589793238462643383279502884 / 180.0)), sn, cs);
+    float cos_t = (float)cs, sin_t = (float)sn;
+    const float bins_per_rad = n / 360.f, exp_scale = -1.f / (d * d * 0.5f), hist_width = 3.f * scl;
+    int radius = __float2int_rn(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
+    const int rmax = (int)sqrt(((double)w) * w + ((double)h) * h);
+    if (radius > rmax) radius = rmax;
+    cos_t /= hist_width; sin_t /= hist_width;
+    volatile float (*part)[8] = s_part[wv];
+    for (int i = lane; i < 360 * 8; i += 64) ((volatile float *)part)[i] = 0.f;
+    const int side = 2 * radius + 1, nsamp = side * side;
+    for (int k0 = 0; k0 < nsamp; k0 += 64) {
+        const int k = k0 + lane;
+        bool valid = k < nsamp;
+        int idx = 0;
+        float v000 = 0, v001 = 0, v010 = 0, v011 = 0, v100 = 0, v101 = 0, v110 = 0, v111 = 0;
+        if (valid) {
+            const int i = k / side - radius, j = k % side - radius;
+            const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
+            float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
+            const int r = py + i, c = px + j;
+            valid = rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1;
+            if (valid) {
+                const float dx = img_l[(size_t)r * w + c + 1] - img_l[(size_t)r * w + c - 1];
+                const float dy = img_l[(size_t)(r - 1) * w + c] - img_l[(size_t)(r + 1) * w + c];
+                const float wgt = det_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+                const float oo = fast_atan2_deg(dy, dx);
+                const float mag = sqrtf(dx * dx + dy * dy) * wgt;
+                float obin = (oo - ori) * bins_per_rad;
+                const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+                int o0 = (int)floorf(obin);
+                rbin -= r0; cbin -= c0; obin -= o0;
+                if (o0 < 0) o0 += n;
+                if (o0 >= n) o0 -= n;
+                const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+                const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+                v111 = v_rc11 * obin; v110 = v_rc11 - v111; v101 = v_rc10 * obin; v100 = v_rc10 - v101;
+                v011 = v_rc01 * obin; v010 = v_rc01 - v011; v001 = v_rc00 * obin; v000 = v_rc00 - v001;
+                idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
+            }
+        }
+#pragma unroll
+        for (int rd = 0; rd < 8; ++rd) {
+            if ((lane >> 3) == rd && valid) {
+                const int L = lane & 7;
+                part[idx][L] = part[idx][L] + v000; part[idx + 1][L] = part[idx + 1][L] + v001;
+                part[idx + (n + 2)][L] = part[idx + (n + 2)][L] + v010; part[idx + (n + 3)][L] = part[idx + (n + 3)][L] + v011;
+                part[idx + (d + 2) * (n + 2)][L] = part[idx + (d + 2) * (n + 2)][L] + v100;
+                part[idx + (d + 2) * (n + 2) + 1][L] = part[idx + (d + 2) * (n + 2) + 1][L] + v101;
+                part[idx + (d + 3) * (n + 2)][L] = part[idx + (d + 3) * (n + 2)][L] + v110;
+                part[idx + (d + 3) * (n + 2) + 1][L] = part[idx + (d + 3) * (n + 2) + 1][L] + v111;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    volatile float *hist = s_hist[wv];
+    for (int b = lane; b < 360; b += 64) {
+        float p0 = part[b][0], p1 = part[b][1], p2 = part[b][2], p3 = part[b][3], p4 = part[b][4], p5 = part[b][5], p6 = part[b][6], p7 = part[b][7];
+        p0 = p0 + p4; p1 = p1 + p5; p2 = p2 + p6; p3 = p3 + p7;
+        p0 = p0 + p2; p1 = p1 + p3;
+        hist[b] = p0 + p1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // circular orientation bins, then element e = (i*d + j)*n + k ; lane holds e = lane and lane + 64
+    float dv0, dv1;
+    {
+        auto elem = [&](int e) {
+            const int ij = e >> 3, kb = e & 7, i = ij >> 2, j = ij & 3;
+            const int id = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
+            float v = hist[id + kb];
+            if (kb < 2) v = v + hist[id + n + kb];
+            return v;
+        };
+        dv0 = elem(lane); dv1 = elem(lane + 64);
+    }
+    auto tree64 = [&](float v) {
+#pragma unroll
+        for (int of = 32; of > 0; of >>= 1) { float u = __shfl_down(v, of); if (lane < of) v = v + u; }
+        return __shfl(v, 0);
+    };
+    float thr = sqrtf(tree64(dv0 * dv0 + dv1 * dv1)) * 0.2f;
+    dv0 = dv0 < thr ? dv0 : thr; dv1 = dv1 < thr ? dv1 : thr;
+    const float nrm = sqrtf(tree64(dv0 * dv0 + dv1 * dv1));
+    const float fct = 512.f / (nrm > FLT_EPSILON ? nrm : FLT_EPSILON);
+    int q0 = __float2int_rn(dv0 * fct), q1 = __float2int_rn(dv1 * fct);
+    q0 = q0 < 0 ? 0 : q0 > 255 ? 255 : q0; q1 = q1 < 0 ? 0 : q1 > 255 ? 255 : q1;
+    uint8_t *dst = desc + ((long long)img * dv.kcap + kidx) * 128;
+    dst[lane] = (uint8_t)q0; dst[lane + 64] = (uint8_t)q1;
+}
+
+// ================================================================== host side
+static int s_round_d(double v) { return (int)lrint(v); }
+
+static int sift_gauss_kernel(double sigma, float *k)
+{
+    int ks = s_round_d(sigma * 8 + 1) | 1;
+    double sum = 0, t[64];
+    for (int i = 0; i < ks; ++i) { double x = i - (ks - 1) * 0.5; t[i] = exp(-0.5 * x * x / (sigma * sigma)); sum += t[i]; }
+    for (int i = 0; i < ks; ++i) k[i] = (float)(t[i] / sum);
+    return ks;
+}
+
+#define SCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); return RPE_ERR_HIP; } } while (0)
+
+int rpe_sift_create(rpe_handle *h)
+{
+    RpeSiftState *S = new RpeSiftState();
+    h->sift = S;
+    SiftDev &dv = S->dv;
+    const int W = h->cfg.width, H = h->cfg.height;
+    const int bw = 2 * W, bh = 2 * H, mn = bw < bh ? bw : bh;
+    dv.noct = s_round_d(log((double)mn) / log(2.) - 2) + 1;
+    if (dv.noct > 12) dv.noct = 12;
+    long long go = 0, dof = 0;
+    for (int o = 0; o < dv.noct; ++o) {
+        dv.w[o] = o ? dv.w[o - 1] / 2 : bw; dv.h[o] = o ? dv.h[o - 1] / 2 : bh;
+        dv.goff[o] = go; go += (long long)S_NG * dv.w[o] * dv.h[o];
+        dv.doff[o] = dof; dof += (long long)S_ND * dv.w[o] * dv.h[o];
+    }
+    dv.gstride = go; dv.dstride = dof; dv.tstride = (long long)bw * bh;
+    dv.nfeatures = h->cfg.nfeatures;
+    dv.kcap = h->lay.kcap;
+    dv.seed_cap = 16384;
+    dv.raw_cap = 32768;
+    float kern[6][32]; int ks[6];
+    memset(kern, 0, sizeof(kern));
+    const double sigma = 1.6, kk = pow(2., 1. / S_NOL);
+    float sd = sqrtf(fmaxf((float)(sigma * sigma) - 0.5f * 0.5f * 4, 0.01f));
+    ks[0] = sift_gauss_kernel((double)sd, kern[0]);
+    for (int i = 1; i < S_NG; ++i) {
+        double sp = pow(kk, (double)(i - 1)) * sigma, st = sp * kk;
+        ks[i] = sift_gauss_kernel(sqrt(st * st - sp * sp), kern[i]);
+        if (ks[i] > 31) { h->err = "SIFT kernel too wide"; return RPE_ERR_INVALID; }
+    }
+    SCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_skern), kern, sizeof(kern)));
+    SCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_sks), ks, sizeof(ks)));
+    // row bands for the extrema passes, in the oracle's enumeration order (octave, layer, row)
+    std::vector<SiftBand> bands;
+    for (int o = 0; o < dv.noct; ++o) {
+        if (dv.w[o] <= 2 * S_BORDER || dv.h[o] <= 2 * S_BORDER) continue;
+        int rb = 16384 / dv.w[o]; if (rb < 1) rb = 1;
+        for (int l = 1; l <= S_NOL; ++l)
+            for (int r = S_BORDER; r < dv.h[o] - S_BORDER; r += rb) {
+                int r1 = r + rb < dv.h[o] - S_BORDER ? r + rb : dv.h[o] - S_BORDER;
+                bands.push_back({(short)o, (short)l, r, r1});
+            }
+    }
+    dv.nbands = (int)bands.size();
+    const size_t NI = (size_t)h->n_img_cap;
+    S->raw_pad = dv.raw_cap;
+    SCHK(hipMalloc(&S->d_bands, sizeof(SiftBand) * bands.size()));
+    SCHK(hipMemcpy(S->d_bands, bands.data(), sizeof(SiftBand) * bands.size(), hipMemcpyHostToDevice));
+    SCHK(hipMalloc(&S->d_gauss, sizeof(float) * NI * dv.gstride));
+    SCHK(hipMalloc(&S->d_dog, sizeof(float) * NI * dv.dstride));
+    SCHK(hipMalloc(&S->d_tmp, sizeof(float) * NI * dv.tstride * 2));
+    SCHK(hipMalloc(&S->d_band_cnt, sizeof(int) * NI * dv.nbands));
+    SCHK(hipMalloc(&S->d_band_off, sizeof(int) * NI * dv.nbands));
+    SCHK(hipMalloc(&S->d_seeds, sizeof(unsigned) * NI * dv.seed_cap));
+    SCHK(hipMalloc(&S->d_nseeds, sizeof(int) * NI));
+    SCHK(hipMalloc(&S->d_raw, sizeof(float) * NI * dv.raw_cap * 6));
+    SCHK(hipMalloc(&S->d_nraw, sizeof(int) * NI));
+    SCHK(hipMalloc(&S->d_overflow, sizeof(int) * NI));
+    SCHK(hipMalloc(&S->d_k0, sizeof(unsigned long long) * NI * S->raw_pad));
+    SCHK(hipMalloc(&S->d_k1, sizeof(unsigned long long) * NI * S->raw_pad));
+    SCHK(hipMalloc(&S->d_sidx, sizeof(unsigned) * NI * S->raw_pad));
+    SCHK(hipMalloc(&S->d_fin, sizeof(float) * NI * dv.kcap * 6));
+    return RPE_OK;
+}
+
+void rpe_sift_destroy(rpe_handle *h)
+{
+    RpeSiftState *S = h->sift;
+    if (!S) return;
+    void *p[] = {S->d_gauss, S->d_dog, S->d_tmp, S->d_bands, S->d_band_cnt, S->d_band_off, S->d_seeds, S->d_nseeds, S->d_raw,
+                 S->d_nraw, S->d_overflow, S->d_k0, S->d_k1, S->d_sidx, S->d_fin};
+    for (void *q : p) if (q) hipFree(q);
+    delete S;
+    h->sift = nullptr;
+}
+
+static void sift_blur(rpe_handle *h, const float *src, long long sstride, float *dst, long long dstride, int w, int hh, int kid, int n_img)
+{
+    RpeSiftState *S = h->sift;
+    float *tmp = S->d_tmp + (long long)h->n_img_cap * S->dv.tstride;      // second half of d_tmp: row-pass output
+    hipLaunchKernelGGL(sift_blur_row_kernel, dim3((w + 255) / 256, hh, n_img), dim3(256), 0, h->stream, src, sstride, tmp, S->dv.tstride, w, hh, kid);
+    hipLaunchKernelGGL(sift_blur_col_kernel, dim3((w + 255) / 256, hh, n_img), dim3(256), 0, h->stream, (const float *)tmp, S->dv.tstride, dst, dstride, w, hh, kid);
+}
+
+// d_imgs: n_img tightly packed u8 images already resident (d_a followed by d_b as in the ORB path)
+int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, int nb)
+{
+    RpeSiftState *S = h->sift;
+    const SiftDev &dv = S->dv;
+    const int W = h->cfg.width, H = h->cfg.height, bw = 2 * W, bh = 2 * H;
+    const size_t img = (size_t)W * H;
+    // 1. upsample + initial blur -> gaussian[0][0]
+    for (int part = 0; part < 2; ++part) {
+        const uint8_t *src = part ? d_b : d_a; const int cnt = part ? nb : na, first = part ? na : 0;
+        if (!cnt) continue;
+        hipLaunchKernelGGL(sift_upsample_kernel, dim3((bw + 255) / 256, bh, cnt), dim3(256), 0, h->stream, src, W, H, img,
+                           S->d_tmp + (long long)first * dv.tstride, dv.tstride);
+    }
+    const int n = na + nb;
+    sift_blur(h, S->d_tmp, dv.tstride, S->d_gauss + dv.goff[0], dv.gstride, bw, bh, 0, n);
+    // 2. gaussian pyramid + DoG
+    for (int o = 0; o < dv.noct; ++o) {
+        const int w = dv.w[o], hh = dv.h[o];
+        const long long pn = (long long)w * hh;
+        if (o > 0)
+            hipLaunchKernelGGL(sift_halve_kernel, dim3((w + 255) / 256, hh, n), dim3(256), 0, h->stream,
+                               (const float *)(S->d_gauss + dv.goff[o - 1] + (long long)S_NOL * dv.w[o - 1] * dv.h[o - 1]),
+                               S->d_gauss + dv.goff[o], dv.gstride, dv.w[o - 1], w, hh);
+        for (int i = 1; i < S_NG; ++i)
+            sift_blur(h, S->d_gauss + dv.goff[o] + (i - 1) * pn, dv.gstride, S->d_gauss + dv.goff[o] + i * pn, dv.gstride, w, hh, i, n);
+        hipLaunchKernelGGL(sift_dog_kernel, dim3((unsigned)((pn + 255) / 256), 1, n), dim3(256), 0, h->stream,
+                           (const float *)(S->d_gauss + dv.goff[o]), dv.gstride, S->d_dog + dv.doff[o], dv.dstride, pn);
+    }
+    // 3. seeds (count, scan, emit)
+    hipLaunchKernelGGL(sift_extrema_kernel<false>, dim3(dv.nbands, n), dim3(256), 0, h->stream, (const float *)S->d_dog, dv,
+                       (const SiftBand *)S->d_bands, S->d_band_cnt, (const int *)S->d_band_off, S->d_seeds);
+    hipLaunchKernelGGL(sift_band_scan_kernel, dim3(n), dim3(64), 0, h->stream, (const int *)S->d_band_cnt, S->d_band_off, S->d_nseeds, dv);
+    hipLaunchKernelGGL(sift_extrema_kernel<true>, dim3(dv.nbands, n), dim3(256), 0, h->stream, (const float *)S->d_dog, dv,
+                       (const SiftBand *)S->d_bands, S->d_band_cnt, (const int *)S->d_band_off, S->d_seeds);
+    // 4. refine + orientation -> raw keypoints
+    hipMemsetAsync(S->d_nraw, 0, sizeof(int) * n, h->stream);
+    hipMemsetAsync(S->d_overflow, 0, sizeof(int) * n, h->stream);
+    hipLaunchKernelGGL(sift_refine_kernel, dim3((dv.seed_cap + 3) / 4, n), dim3(256), 0, h->stream, (const float *)S->d_gauss,
+                       (const float *)S->d_dog, dv, (const unsigned *)S->d_seeds, (const int *)S->d_nseeds, S->d_raw, S->d_nraw, S->d_overflow);
+    // 5. sort, dedup, retainBest, compaction
+    hipLaunchKernelGGL(sift_sort_kernel, dim3(n), dim3(1024), 0, h->stream, (const float *)S->d_raw, (const int *)S->d_nraw, dv, S->raw_pad,
+                       S->d_k0, S->d_k1, S->d_sidx);
+    hipLaunchKernelGGL(sift_finalize_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_raw, (const int *)S->d_nraw, dv, S->raw_pad,
+                       (const unsigned long long *)S->d_k0, (const unsigned long long *)S->d_k1, (const unsigned *)S->d_sidx,
+                       S->d_fin, h->d_kp_pt, h->d_kp_count);
+    // 6. descriptors
+    hipLaunchKernelGGL(sift_describe_kernel, dim3((dv.kcap + 3) / 4, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
+                       (const float *)S->d_fin, (const int *)h->d_kp_count, h->d_desc);
+    SCHK(hipGetLastError());
+    return RPE_OK;
+}
+
+// keypoint records of the last run (stage API / tests): fin rows x,y,size,angle,response,octave(bits) un-halved
+int rpe_sift_fetch(rpe_handle *h, int n_images, float *fin_host, int *counts)
+{
+    RpeSiftState *S = h->sift;
+    SCHK(hipMemcpyAsync(fin_host, S->d_fin, sizeof(float) * 6 * (size_t)n_images * S->dv.kcap, hipMemcpyDeviceToHost, h->stream));
+    SCHK(hipMemcpyAsync(counts, h->d_kp_count, sizeof(int) * n_images, hipMemcpyDeviceToHost, h->stream));
+    SCHK(hipStreamSynchronize(h->stream));
+    return RPE_OK;
+}
+
+int rpe_sift_fetch_gauss(rpe_handle *h, int index, float *out)
+{
+    RpeSiftState *S = h->sift;
+    SCHK(hipMemcpyAsync(out, S->d_gauss + (long long)index * S->dv.gstride, sizeof(float) * S->dv.gstride, hipMemcpyDeviceToHost, h->stream));
+    SCHK(hipStreamSynchronize(h->stream));
+    return RPE_OK;
+}
+long long rpe_sift_gauss_floats(rpe_handle *h) { return h->sift ? h->sift->dv.gstride : 0; }
