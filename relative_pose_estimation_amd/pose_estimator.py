@@ -6,7 +6,7 @@ estimate_with_debug(...) -> dict with the reference's keys (:571-688, dict
 :624-633), same exception types and messages (:96, :129, :508-509, :514-515,
 :529-530).  Added: estimate_batch() for many pairs per call.
 
-Scope: the feature -> match -> essential -> pose path.  VP refinement
+Scope: the feature -> match -> essential -> pose path (ORB + Hamming, SIFT + L2).  VP refinement
 (:160-481, :536-567) is outside the accelerated path: the
 kwargs are accepted and stored; requesting it has no effect on R here and
 'vp_used' is always False.
@@ -63,8 +63,9 @@ class PoseEstimator:
             self._norm = _capi.NORM_L2
         else:
             raise ValueError(f"Unknown norm type: {norm}")
-        if self._feature != _capi.FEATURE_ORB or self._norm != _capi.NORM_HAMMING:
-            raise NotImplementedError("the MI355X path implements ORB + Hamming (SIFT + L2 is a later scope row)")
+        if (self._feature, self._norm) not in ((_capi.FEATURE_ORB, _capi.NORM_HAMMING), (_capi.FEATURE_SIFT, _capi.NORM_L2)):
+            # cv2 itself rejects Hamming on float descriptors; ORB + L2 is legal in cv2 but not built here
+            raise NotImplementedError("the MI355X path implements ORB + Hamming and SIFT + L2")
         self._engines = {}
 
     def _engine(self, height, width, batch):
@@ -74,7 +75,10 @@ class PoseEstimator:
             if eng is not None:
                 eng.close()
             mm = self.max_matches if self.max_matches is not None else self.nfeatures + 64
-            eng = _capi.Engine(width, height, max_batch=max(batch, self.max_batch), nfeatures=self.nfeatures,
+            # SIFT: the reference's SIFT_create() is uncapped (nfeatures is documented "ORB only",
+            # pose_estimator.py:41); the GPU workspace needs a bound, so nfeatures caps SIFT too (<= 4032)
+            nf = min(self.nfeatures, 4032) if self._feature == _capi.FEATURE_SIFT else self.nfeatures
+            eng = _capi.Engine(width, height, max_batch=max(batch, self.max_batch), nfeatures=nf,
                                max_matches=mm, device=self.device, feature_method=self._feature, norm_type=self._norm)
             self._engines[key] = eng
         return eng
