@@ -68,7 +68,7 @@ def pmc_traffic(stage, pairs_per_launch, W, H, nfeatures):
     return k["hbm_bytes_per_launch"] if k else None
 
 
-def cpu_baseline(i1, i2, K, nfeatures, max_matches, sample):
+def cpu_baseline(i1, i2, K, nfeatures, max_matches, sample, method="ORB"):
     """The oracle (a scalar C port of the reference's cv2 calls) timed on this host's
     cores on a bounded sample of the same workload."""
     from oracle import oracle
@@ -78,10 +78,10 @@ def cpu_baseline(i1, i2, K, nfeatures, max_matches, sample):
     n = min(sample, len(i1))
     threads = min(cores, n)
     t0 = time.perf_counter()
-    res = oracle.estimate_pose_batch(i1[:n], i2[:n], K, nfeatures, max_matches, nthreads=threads)
+    res = oracle.estimate_pose_batch(i1[:n], i2[:n], K, nfeatures, max_matches, nthreads=threads, method=method)
     dt = time.perf_counter() - t0
     return res, {"value": n / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-                 "sample": f"first {n} pairs of the same synthetic batch (640x480, ORB {nfeatures}), "
+                 "sample": f"first {n} pairs of the same synthetic batch ({i1.shape[2]}x{i1.shape[1]}, {method} {nfeatures}), "
                            f"{threads} pthreads over pairs, {dt:.1f} s wall"}
 
 
@@ -98,6 +98,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gen-workers", type=int, default=0)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3],
+                    help="BASELINE configs[]: 2 = 1024 VGA pairs ORB(1000)+Hamming (the metric's config, default); "
+                         "3 = 1920x1080 pairs SIFT(2048)+L2, processed in sub-batches")
+    ap.add_argument("--sub-batch", type=int, default=0, help="pairs per enqueue (config 3 default 32: 1.1 GB of pyramid per pair)")
     ap.add_argument("--streams", type=int, default=1, help="split the batch over S engine handles (S HIP streams) so latency-bound stages overlap")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of the N>1 path)")
     ap.add_argument("--data-cache", default="", help="npz file to load/save the synthetic batch (keeps forks out of profiled runs)")
@@ -122,7 +126,19 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
+    method = "ORB"
+    if args.config == 3:
+        method = "SIFT"
+        if args.width == 640 and args.height == 480:
+            args.width, args.height = 1920, 1080
+        if args.nfeatures == 1000:
+            args.nfeatures = 2048
+        if args.batch == 1024:
+            args.batch = 128
+        if args.cpu_sample == 128:
+            args.cpu_sample = 16
     W, H, B = args.width, args.height, args.batch
+    sub = args.sub_batch or (32 if method == "SIFT" else B)
     K = geometry.default_camera_matrix(W, H)
     cores = os.cpu_count() or 1
     workers = args.gen_workers or max(1, min(16, cores // max(1, world)))
@@ -144,7 +160,9 @@ def main():
         gather_dev = torch.device("cuda", local_rank)
     S = max(1, args.streams)
     bounds = [sharding.shard_bounds(B, s, S) for s in range(S)]
-    engs = [_capi.Engine(W, H, max_batch=hi - lo, nfeatures=args.nfeatures, max_matches=args.max_matches, device=device)
+    fm, nt = (_capi.FEATURE_SIFT, _capi.NORM_L2) if method == "SIFT" else (_capi.FEATURE_ORB, _capi.NORM_HAMMING)
+    engs = [_capi.Engine(W, H, max_batch=min(sub, hi - lo), nfeatures=args.nfeatures, max_matches=args.max_matches, device=device,
+                         feature_method=fm, norm_type=nt)
             for lo, hi in bounds]
     eng = engs[0]
     dbuf = [(e.upload(i1[lo:hi]), e.upload(i2[lo:hi])) for e, (lo, hi) in zip(engs, bounds)]   # inputs resident in HBM
@@ -159,10 +177,24 @@ def main():
             if gather_dev is not None:
                 torch.cuda.synchronize()
 
+    sub_acc = {}
+
     def step():
-        for e, (a, b), (lo, hi) in zip(engs, dbuf, bounds):
-            e.enqueue_batch_device(a, b, hi - lo, K)
-        parts = [e.fetch_results(hi - lo) for e, (lo, hi) in zip(engs, bounds)]
+        if sub >= B:
+            for e, (a, b), (lo, hi) in zip(engs, dbuf, bounds):
+                e.enqueue_batch_device(a, b, hi - lo, K)
+            parts = [e.fetch_results(hi - lo) for e, (lo, hi) in zip(engs, bounds)]
+        else:                       # sub-batched (workspace-bound configs): one engine, consecutive slices
+            import ctypes
+            parts = []
+            (a, b), e = dbuf[0], engs[0]
+            for lo in range(0, B, sub):
+                n = min(sub, B - lo)
+                off = lo * W * H
+                e.enqueue_batch_device(ctypes.c_void_p(a.value + off), ctypes.c_void_p(b.value + off), n, K)
+                parts.append(e.fetch_results(n))
+                for k, v in e.stage_ms().items():
+                    sub_acc[k] = sub_acc.get(k, 0.0) + v
         R, t, inl, nm, st = (np.concatenate([p[k] for p in parts]) for k in range(5))
         rec = sharding.pack_records(R, t, inl, st, nm, first_pair=rank * B)
         if dist is not None:
@@ -176,9 +208,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rec, local = step()
-        for e in engs:
-            for k, v in e.stage_ms().items():
-                stage_acc[k] = stage_acc.get(k, 0.0) + v
+        if sub >= B:
+            for e in engs:
+                for k, v in e.stage_ms().items():
+                    stage_acc[k] = stage_acc.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -192,14 +225,21 @@ def main():
     # per-LAUNCH averages: every step launches each kernel group once per stream on B/S pairs
     stage_ms = {k: v / (args.steps * S) for k, v in stage_acc.items()}
     Bl = B // S if B % S == 0 else B / S          # pairs per launch
+    if sub < B:
+        Bl = sub
+        launches = (args.steps + args.warmup) * (-(-B // sub))
+        stage_ms = {k: v / launches for k, v in sub_acc.items()}
     pyr_px = eng.lib.rpe_orb_pyramid_pixels(eng.h)
 
     if rank == 0:
         dom = max(stage_ms, key=stage_ms.get)
-        dom_bytes = stage_bytes(dom, W, H, pyr_px, args.nfeatures, args.max_matches) * Bl
+        if method == "SIFT":
+            dom = "match"          # SIFT extraction is a multi-kernel group; the roofline line prices the L2 matcher
+        dom_bytes = stage_bytes(dom, W, H, pyr_px, args.nfeatures, args.max_matches) * Bl if method == "ORB" else \
+            (2 * args.nfeatures * 128 + args.nfeatures * 8) * Bl
         achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
         # the matcher is the stage north_star attaches a roofline target to: always report it too
-        m_bytes = stage_bytes("match", W, H, pyr_px, args.nfeatures, args.max_matches) * Bl
+        m_bytes = stage_bytes("match", W, H, pyr_px, args.nfeatures, args.max_matches) * Bl if method == "ORB" else dom_bytes
         m_achieved = m_bytes / (stage_ms["match"] * 1e-3) / 1e9
         out = {
             "metric": "image-pairs/s end-to-end (640x480 pairs), median rotation-angle error alongside",
@@ -214,8 +254,10 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/i32 (ORB, Hamming) + f64 (RANSAC, pose)",
             "data": "synthetic",
-            "config": {"workload": f"{B} {W}x{H} pairs per GPU, ORB({args.nfeatures}kp)+BF-Hamming crossCheck top-{args.max_matches}"
-                                   "+5pt-RANSAC(0.999,1px)+recoverPose (BASELINE configs[1])",
+            "config": {"workload": (f"{B} {W}x{H} pairs per GPU, ORB({args.nfeatures}kp)+BF-Hamming crossCheck top-{args.max_matches}"
+                                    "+5pt-RANSAC(0.999,1px)+recoverPose (BASELINE configs[1])") if method == "ORB" else
+                                   (f"{B} {W}x{H} pairs per GPU in sub-batches of {sub}, SIFT(cap {args.nfeatures})+BF-L2 crossCheck "
+                                    f"top-{args.max_matches}+5pt-RANSAC+recoverPose (BASELINE configs[2] shape, reduced pair count)"),
                        "pairs_per_gpu": B, "global_pairs": world * B, "streams_per_gpu": S, "pairs_per_launch": Bl, "sharding": f"pairs x{world}, RCCL all-gather of 128-B pose records"},
             "median_rotation_error_deg": float(np.median(errs)) if len(errs) else None,
             "pairs_ok": int(ok.sum()),
@@ -227,7 +269,7 @@ def main():
                                      "algorithmic_bytes_per_launch": m_bytes, "avg_launch_ms": stage_ms["match"]}},
         }
         if not args.no_cpu_baseline and world == 1:
-            res, cb = cpu_baseline(i1, i2, K, args.nfeatures, args.max_matches, args.cpu_sample)
+            res, cb = cpu_baseline(i1, i2, K, args.nfeatures, args.max_matches, args.cpu_sample, method)
             n = len(res)
             cerr = [geometry.rotation_error(res["R"][i].reshape(3, 3), Rgt[i]) for i in range(n) if res["status"][i] == 0]
             cb["median_rotation_error_deg"] = float(np.median(cerr)) if cerr else None

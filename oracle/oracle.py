@@ -206,11 +206,14 @@ def estimate_pose(img1, img2, K, nfeatures=4000, max_matches=500):
             "inliers": res.inliers, "R": np.array(res.R).reshape(3, 3), "t": np.array(res.t).reshape(3, 1)}
 
 
-def estimate_pose_batch(imgs1, imgs2, K, nfeatures=4000, max_matches=500, nthreads=1):
+def estimate_pose_batch(imgs1, imgs2, K, nfeatures=4000, max_matches=500, nthreads=1, method="ORB"):
     imgs1 = np.ascontiguousarray(imgs1, np.uint8); imgs2 = np.ascontiguousarray(imgs2, np.uint8)
     K = np.ascontiguousarray(K, np.float64)
     B, H, W = imgs1.shape
     out = np.zeros(B, POSE_DTYPE)
+    if method.upper() == "SIFT":
+        lib().orc_estimate_pose_sift_batch(_p(imgs1), _p(imgs2), B, W, H, _p(K), nfeatures, max_matches, _p(out), nthreads)
+        return out
     lib().orc_estimate_pose_batch(_p(imgs1), _p(imgs2), B, W, H, _p(K), nfeatures, max_matches, _p(out), nthreads)
     return out
 
@@ -218,9 +221,10 @@ def estimate_pose_batch(imgs1, imgs2, K, nfeatures=4000, max_matches=500, nthrea
 SIFT_KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4")])
 
 
-def sift_detect_and_compute(img, nfeatures=0, seed_cap=32768, cap=None):
+def sift_detect_and_compute(img, nfeatures=0, seed_cap=None, cap=None):
     img = np.ascontiguousarray(img, np.uint8)
     H, W = img.shape
+    seed_cap = seed_cap or max(16384, 4 * W * H // 16)      # the HIP path's workspace rule
     cap = cap or (nfeatures + 64 if nfeatures > 0 else 4 * seed_cap)
     kps = np.zeros(cap, SIFT_KP_DTYPE); desc = np.zeros((cap, 128), np.float32)
     n = lib().orc_sift_detect_and_compute(_p(img), W, H, int(nfeatures), int(seed_cap), _p(kps), _p(desc), cap)

@@ -483,3 +483,61 @@ int64_t orc_sift_gauss_pyramid(const uint8_t *img, int W, int H, float *out, int
 }
 
 float orc_det_expf(float x) { return det_expf(x); }
+
+
+/* ---------------------------------------------------------- end to end (SIFT + L2) */
+int orc_estimate_pose_sift(const uint8_t *img1, const uint8_t *img2, int W, int H, const double *K,
+                           int nfeatures, int max_matches, orc_pose_result *out)
+{
+    memset(out, 0, sizeof(*out));
+    int cap = nfeatures > 0 ? nfeatures + 64 : 65536;
+    orc_sift_keypoint *k1 = (orc_sift_keypoint *)malloc(sizeof(orc_sift_keypoint) * 2 * (size_t)cap), *k2 = k1 + cap;
+    float *d1 = (float *)malloc(sizeof(float) * 256 * (size_t)cap), *d2 = d1 + 128 * (size_t)cap;
+    int seed_cap = (int)(((long long)4 * W * H) / 16); if (seed_cap < 16384) seed_cap = 16384;   /* rule of the HIP path */
+    int n1 = orc_sift_detect_and_compute(img1, W, H, nfeatures, seed_cap, k1, d1, cap);
+    int n2 = orc_sift_detect_and_compute(img2, W, H, nfeatures, seed_cap, k2, d2, cap);
+    out->n_kp1 = n1; out->n_kp2 = n2;
+    int mm = max_matches >= 0 ? max_matches : cap;
+    int32_t *qi = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)cap), *ti = qi + cap;
+    float *di = (float *)malloc(sizeof(float) * (size_t)cap);
+    float *p1 = (float *)malloc(sizeof(float) * 4 * (size_t)cap), *p2 = p1 + 2 * (size_t)cap;
+    if (n1 == 0 || n2 == 0) { out->status = ORC_NO_DESCRIPTORS; goto done; }
+    int M = orc_match_l2(d1, n1, d2, n2, 128, mm, qi, ti, di);
+    out->n_matches = M;
+    if (M < 5) { out->status = ORC_INSUFFICIENT_MATCHES; goto done; }
+    for (int i = 0; i < M; ++i) {
+        p1[2 * i] = k1[qi[i]].x; p1[2 * i + 1] = k1[qi[i]].y;
+        p2[2 * i] = k2[ti[i]].x; p2[2 * i + 1] = k2[ti[i]].y;
+    }
+    double E[9];
+    if (!orc_find_essential(p1, p2, M, K, 0.999, 1.0, 1000, E, NULL, NULL)) { out->status = ORC_NO_ESSENTIAL; goto done; }
+    out->inliers = orc_recover_pose(E, p1, p2, M, K, out->R, out->t);
+    out->status = ORC_OK;
+done:
+    free(p1); free(di); free(qi); free(d1); free(k1);
+    return out->status;
+}
+
+#include <pthread.h>
+typedef struct { const uint8_t *i1, *i2; int B, W, H; const double *K; int nf, mm; orc_pose_result *out; int tid, nt; } sjob_t;
+static void *sift_worker(void *arg)
+{
+    sjob_t *j = (sjob_t *)arg;
+    size_t sz = (size_t)j->W * j->H;
+    for (int b = j->tid; b < j->B; b += j->nt)
+        orc_estimate_pose_sift(j->i1 + sz * b, j->i2 + sz * b, j->W, j->H, j->K, j->nf, j->mm, &j->out[b]);
+    return NULL;
+}
+void orc_estimate_pose_sift_batch(const uint8_t *imgs1, const uint8_t *imgs2, int B, int W, int H, const double *K,
+                                  int nfeatures, int max_matches, orc_pose_result *out, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256]; sjob_t jb[256];
+    for (int t = 0; t < nthreads; ++t) {
+        sjob_t j = {imgs1, imgs2, B, W, H, K, nfeatures, max_matches, out, t, nthreads};
+        jb[t] = j;
+        pthread_create(&th[t], NULL, sift_worker, &jb[t]);
+    }
+    for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+}

@@ -276,7 +276,7 @@ extern "C" int rpe_create(const rpe_config *cfg, rpe_handle **out)
           (is_sift && cfg->norm_type == RPE_NORM_L2))) {
         g_create_err = "supported combinations: ORB + Hamming, SIFT + L2"; return RPE_ERR_INVALID;
     }
-    if (is_sift && (cfg->nfeatures > 4032 || cfg->width > 4000 || cfg->height > 4000)) {
+    if (is_sift && (cfg->nfeatures > 4032 || cfg->nfeatures < 1 || cfg->width > 4000 || cfg->height > 4000)) {
         g_create_err = "SIFT: nfeatures (keypoint cap) must be <= 4032 and the image <= 4000 px"; return RPE_ERR_INVALID;
     }
     if (cfg->width < 96 || cfg->height < 96 || cfg->width > 4095 || cfg->height > 4095 || cfg->max_batch < 1 ||

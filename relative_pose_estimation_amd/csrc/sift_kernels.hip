@@ -50,7 +50,7 @@ struct RpeSiftState {
     int *d_band_cnt = nullptr, *d_band_off = nullptr;     // [img][nbands]
     unsigned *d_seeds = nullptr; int *d_nseeds = nullptr; // [img][seed_cap], [img]
     float *d_raw = nullptr;                                // [img][raw_cap][6]: x y size angle response octave(bits)
-    int *d_nraw = nullptr, *d_overflow = nullptr;
+    int *d_nraw = nullptr, *d_overflow = nullptr, *d_ncand = nullptr;
     unsigned long long *d_k0 = nullptr, *d_k1 = nullptr; unsigned *d_sidx = nullptr; // sort keys [img][raw_pad]
     int raw_pad = 0;
     float *d_fin = nullptr;                                // [img][kcap][6] un-halved keypoints in sorted order
@@ -372,25 +372,83 @@ __global__ __launch_bounds__(256) void sift_refine_kernel(const float *__restric
 // ------------------------------------------------------------------ sort
 // KeyPoint_LessThan as a 128-bit key: (x, y) ascending, size descending, angle ascending.
 // Exact duplicates (same seed end point) get identical keys and become neighbours.
-__global__ __launch_bounds__(1024) void sift_sort_kernel(const float *__restrict__ raw, const int *__restrict__ nraw, SiftDev dv, int pad,
+__device__ __forceinline__ unsigned s_float_key(float f)
+{
+    unsigned u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// Response prefilter: retainBest(nfeatures) only ever keeps the strongest keypoints, so only the
+// K = 2*nfeatures + 1024 strongest raw entries (ties included) go through the sort.  Equivalent
+// to OpenCV's dedup -> retainBest as long as the top K hold >= nfeatures unique keypoints
+// (exact duplicates are rare); otherwise the overflow flag is raised.
+__global__ __launch_bounds__(256) void sift_prefilter_kernel(const float *__restrict__ raw, const int *__restrict__ nraw, SiftDev dv, int pad,
+                                                              unsigned long long *__restrict__ k0, unsigned long long *__restrict__ k1,
+                                                              unsigned *__restrict__ sidx, int *__restrict__ ncand, int *__restrict__ overflow)
+{
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_prefix;
+    __shared__ int s_kk, s_cnt;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int n = min(nraw[img], dv.raw_cap);
+    const float *rw = raw + (long long)img * dv.raw_cap * 6;
+    const int K = 2 * dv.nfeatures + 1024;
+    unsigned thr_key = 0;
+    if (dv.nfeatures > 0 && n > K) {
+        unsigned prefix = 0, mask = 0;
+        if (tid == 0) s_kk = K;
+        for (int pass = 3; pass >= 0; --pass) {
+            const int shift = 8 * pass;
+            s_hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += 256) {
+                unsigned key = s_float_key(rw[(long long)i * 6 + 4]);
+                if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int kk = s_kk, acc = 0, bin = 0;
+                for (int b = 255; b >= 0; --b) { int c = (int)s_hist[b]; if (acc + c >= kk) { bin = b; break; } acc += c; }
+                s_kk = kk - acc;
+                s_prefix = prefix | ((unsigned)bin << shift);
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            mask |= 255u << shift;
+        }
+        thr_key = prefix;
+    }
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    unsigned long long *a0 = k0 + (long long)img * pad, *a1 = k1 + (long long)img * pad;
+    unsigned *ix = sidx + (long long)img * pad;
+    for (int i = tid; i < n; i += 256) {
+        const float *q = rw + (long long)i * 6;
+        if (s_float_key(q[4]) >= thr_key) {
+            const int slot = atomicAdd(&s_cnt, 1);               // order is irrelevant: the list is sorted next
+            if (slot < pad) {
+                a0[slot] = ((unsigned long long)__float_as_uint(q[0]) << 32) | __float_as_uint(q[1]);   // x, y > 0: bit order = value order
+                a1[slot] = ((unsigned long long)(~__float_as_uint(q[2])) << 32) | __float_as_uint(q[3]);
+                ix[slot] = (unsigned)i;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { ncand[img] = min(s_cnt, pad); if (s_cnt > pad) overflow[img] = 1; }
+}
+
+__global__ __launch_bounds__(1024) void sift_sort_kernel(const int *__restrict__ ncand, int pad,
                                                           unsigned long long *__restrict__ k0, unsigned long long *__restrict__ k1,
                                                           unsigned *__restrict__ sidx)
 {
     const int img = blockIdx.x, tid = threadIdx.x;
-    const int n = min(nraw[img], dv.raw_cap);
+    const int n = ncand[img];
     int P = 64;
     while (P < n) P <<= 1;
     unsigned long long *a0 = k0 + (long long)img * pad, *a1 = k1 + (long long)img * pad;
     unsigned *ix = sidx + (long long)img * pad;
-    for (int i = tid; i < P; i += 1024) {
-        unsigned long long u0 = ~0ull, u1 = ~0ull;
-        if (i < n) {
-            const float *q = raw + ((long long)img * dv.raw_cap + i) * 6;
-            u0 = ((unsigned long long)__float_as_uint(q[0]) << 32) | __float_as_uint(q[1]);     // x, y > 0: bit order = value order
-            u1 = ((unsigned long long)(~__float_as_uint(q[2])) << 32) | __float_as_uint(q[3]);
-        }
-        a0[i] = u0; a1[i] = u1; ix[i] = (unsigned)i;
-    }
+    for (int i = n + tid; i < P; i += 1024) { a0[i] = ~0ull; a1[i] = ~0ull; ix[i] = 0xFFFFFFFFu; }
     __syncthreads();
     for (int k = 2; k <= P; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -398,7 +456,6 @@ __global__ __launch_bounds__(1024) void sift_sort_kernel(const float *__restrict
                 const int i = 2 * j * (t / j) + (t % j), ixj = i + j;
                 const bool asc = (i & k) == 0;
                 const unsigned long long x0 = a0[i], x1 = a1[i], y0 = a0[ixj], y1 = a1[ixj];
-                // the payload index breaks ties so the result does not depend on the append order
                 const unsigned xi = ix[i], yi = ix[ixj];
                 const bool gt = x0 > y0 || (x0 == y0 && (x1 > y1 || (x1 == y1 && xi > yi)));
                 if (gt == asc) { a0[i] = y0; a1[i] = y1; ix[i] = yi; a0[ixj] = x0; a1[ixj] = x1; ix[ixj] = xi; }
@@ -408,14 +465,7 @@ __global__ __launch_bounds__(1024) void sift_sort_kernel(const float *__restrict
 }
 
 // ---------------------------------------------------------------- finalize
-__device__ __forceinline__ unsigned s_float_key(float f)
-{
-    unsigned u = __float_as_uint(f);
-    if (u == 0x80000000u) u = 0;
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-__global__ __launch_bounds__(256) void sift_finalize_kernel(const float *__restrict__ raw, const int *__restrict__ nraw, SiftDev dv, int pad,
+__global__ __launch_bounds__(256) void sift_finalize_kernel(const float *__restrict__ raw, const int *__restrict__ ncand, SiftDev dv, int pad,
                                                              const unsigned long long *__restrict__ k0, const unsigned long long *__restrict__ k1,
                                                              const unsigned *__restrict__ sidx, float *__restrict__ fin,
                                                              float2 *__restrict__ kp_pt, int *__restrict__ kp_count)
@@ -425,7 +475,7 @@ __global__ __launch_bounds__(256) void sift_finalize_kernel(const float *__restr
     __shared__ unsigned s_prefix;
     __shared__ int s_kk, s_nuniq;
     const int img = blockIdx.x, tid = threadIdx.x;
-    const int n = min(nraw[img], dv.raw_cap);
+    const int n = ncand[img];
     const unsigned long long *a0 = k0 + (long long)img * pad, *a1 = k1 + (long long)img * pad;
     const unsigned *ix = sidx + (long long)img * pad;
     const float *rw = raw + (long long)img * dv.raw_cap * 6;
@@ -628,8 +678,9 @@ int rpe_sift_create(rpe_handle *h)
     dv.gstride = go; dv.dstride = dof; dv.tstride = (long long)bw * bh;
     dv.nfeatures = h->cfg.nfeatures;
     dv.kcap = h->lay.kcap;
-    dv.seed_cap = 16384;
-    dv.raw_cap = 32768;
+    // seeds: 1/16 of the base-image pixels (>= 16384); the oracle uses the same bound
+    dv.seed_cap = (int)(((long long)bw * bh) / 16); if (dv.seed_cap < 16384) dv.seed_cap = 16384;
+    dv.raw_cap = dv.seed_cap;
     float kern[6][32]; int ks[6];
     memset(kern, 0, sizeof(kern));
     const double sigma = 1.6, kk = pow(2., 1. / S_NOL);
@@ -655,7 +706,7 @@ int rpe_sift_create(rpe_handle *h)
     }
     dv.nbands = (int)bands.size();
     const size_t NI = (size_t)h->n_img_cap;
-    S->raw_pad = dv.raw_cap;
+    S->raw_pad = 16384;                       // sort capacity: candidates after the response prefilter
     SCHK(hipMalloc(&S->d_bands, sizeof(SiftBand) * bands.size()));
     SCHK(hipMemcpy(S->d_bands, bands.data(), sizeof(SiftBand) * bands.size(), hipMemcpyHostToDevice));
     SCHK(hipMalloc(&S->d_gauss, sizeof(float) * NI * dv.gstride));
@@ -668,6 +719,7 @@ int rpe_sift_create(rpe_handle *h)
     SCHK(hipMalloc(&S->d_raw, sizeof(float) * NI * dv.raw_cap * 6));
     SCHK(hipMalloc(&S->d_nraw, sizeof(int) * NI));
     SCHK(hipMalloc(&S->d_overflow, sizeof(int) * NI));
+    SCHK(hipMalloc(&S->d_ncand, sizeof(int) * NI));
     SCHK(hipMalloc(&S->d_k0, sizeof(unsigned long long) * NI * S->raw_pad));
     SCHK(hipMalloc(&S->d_k1, sizeof(unsigned long long) * NI * S->raw_pad));
     SCHK(hipMalloc(&S->d_sidx, sizeof(unsigned) * NI * S->raw_pad));
@@ -680,7 +732,7 @@ void rpe_sift_destroy(rpe_handle *h)
     RpeSiftState *S = h->sift;
     if (!S) return;
     void *p[] = {S->d_gauss, S->d_dog, S->d_tmp, S->d_bands, S->d_band_cnt, S->d_band_off, S->d_seeds, S->d_nseeds, S->d_raw,
-                 S->d_nraw, S->d_overflow, S->d_k0, S->d_k1, S->d_sidx, S->d_fin};
+                 S->d_nraw, S->d_overflow, S->d_ncand, S->d_k0, S->d_k1, S->d_sidx, S->d_fin};
     for (void *q : p) if (q) hipFree(q);
     delete S;
     h->sift = nullptr;
@@ -735,9 +787,10 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
     hipLaunchKernelGGL(sift_refine_kernel, dim3((dv.seed_cap + 3) / 4, n), dim3(256), 0, h->stream, (const float *)S->d_gauss,
                        (const float *)S->d_dog, dv, (const unsigned *)S->d_seeds, (const int *)S->d_nseeds, S->d_raw, S->d_nraw, S->d_overflow);
     // 5. sort, dedup, retainBest, compaction
-    hipLaunchKernelGGL(sift_sort_kernel, dim3(n), dim3(1024), 0, h->stream, (const float *)S->d_raw, (const int *)S->d_nraw, dv, S->raw_pad,
-                       S->d_k0, S->d_k1, S->d_sidx);
-    hipLaunchKernelGGL(sift_finalize_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_raw, (const int *)S->d_nraw, dv, S->raw_pad,
+    hipLaunchKernelGGL(sift_prefilter_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_raw, (const int *)S->d_nraw, dv, S->raw_pad,
+                       S->d_k0, S->d_k1, S->d_sidx, S->d_ncand, S->d_overflow);
+    hipLaunchKernelGGL(sift_sort_kernel, dim3(n), dim3(1024), 0, h->stream, (const int *)S->d_ncand, S->raw_pad, S->d_k0, S->d_k1, S->d_sidx);
+    hipLaunchKernelGGL(sift_finalize_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_raw, (const int *)S->d_ncand, dv, S->raw_pad,
                        (const unsigned long long *)S->d_k0, (const unsigned long long *)S->d_k1, (const unsigned *)S->d_sidx,
                        S->d_fin, h->d_kp_pt, h->d_kp_count);
     // 6. descriptors

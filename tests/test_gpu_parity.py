@@ -270,7 +270,7 @@ def test_sift_bit_exact(eng_sift, oracle):
         go, dims = oracle.sift_gauss_pyramid(imgs[n])
         gg = eng_sift.sift_debug_gauss(n)
         assert gg.shape == go.shape and np.array_equal(gg.view(np.uint32), go.view(np.uint32)), "gaussian pyramid differs"
-        ko, do = oracle.sift_detect_and_compute(imgs[n], nfeatures=600, seed_cap=16384, cap=664)
+        ko, do = oracle.sift_detect_and_compute(imgs[n], nfeatures=600, cap=664)
         assert cnt[n] == len(ko), (cnt[n], len(ko))
         kg = kps[n, :cnt[n]]
         for f in ("x", "y", "size", "angle", "response"):
@@ -285,7 +285,7 @@ def test_sift_end_to_end(capi, eng_sift, oracle):
     i1, i2, Rgt, _ = synthetic.make_batch(2, K, 320, 240, cfg=6)
     R, t, inl, nm, st = eng_sift.estimate_batch(i1, i2, K)
     for n in range(2):
-        k1, d1 = oracle.sift_detect_and_compute(i1[n], 600, 16384, 664); k2, d2 = oracle.sift_detect_and_compute(i2[n], 600, 16384, 664)
+        k1, d1 = oracle.sift_detect_and_compute(i1[n], 600, None, 664); k2, d2 = oracle.sift_detect_and_compute(i2[n], 600, None, 664)
         q, tt, d = oracle.match_l2(d1, d2, 300)
         p1 = np.stack([k1["x"][q], k1["y"][q]], 1); p2 = np.stack([k2["x"][tt], k2["y"][tt]], 1)
         E, m, info = oracle.find_essential(p1, p2, K)
