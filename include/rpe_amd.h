@@ -133,6 +133,13 @@ int rpe_enqueue_batch_device(rpe_handle *h, const uint8_t *d_imgs1, const uint8_
                              const double K[9]);
 int rpe_fetch_results(rpe_handle *h, int B, double *R, double *t, int32_t *inliers,
                       int32_t *n_matches, int32_t *status);
+/* Consecutive-frame stream = the pair loop of BatchProcessor.process_sequence (reference
+ * src/core/batch_processor.py:71-109): F frames -> F-1 relative poses (frame i -> i+1), features
+ * extracted once per frame.  F <= 2*max_batch, F-1 <= max_batch.  Outputs sized F-1. */
+int rpe_estimate_stream(rpe_handle *h, const uint8_t *h_frames, int F, const double K[9],
+                        double *R, double *t, int32_t *inliers, int32_t *n_matches, int32_t *status);
+int rpe_enqueue_stream_device(rpe_handle *h, const uint8_t *d_frames, int F, const double K[9]);
+
 /* matched point arrays of the last batch (estimate_with_debug's pts1/pts2,
  * pose_estimator.py:606-607,628-629): pts[B*max_matches*2] f32 */
 int rpe_fetch_matched_points(rpe_handle *h, int B, float *pts1, float *pts2);

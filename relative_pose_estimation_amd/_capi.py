@@ -26,6 +26,7 @@ EXPORTS = [
     "rpe_orb_pyramid_pixels", "rpe_match_hamming", "rpe_find_essential", "rpe_recover_pose",
     "rpe_set_profiling", "rpe_get_stage_ms", "rpe_stage_name",
     "rpe_sift_detect_and_compute", "rpe_sift_debug_gauss", "rpe_match_l2",
+    "rpe_estimate_stream", "rpe_enqueue_stream_device",
 ]
 
 
@@ -95,6 +96,8 @@ def load():
     lib.rpe_sift_debug_gauss.argtypes = [vp, C.c_int, vp]; lib.rpe_sift_debug_gauss.restype = C.c_int64
     lib.rpe_match_l2.argtypes = [vp, vp, i32p, vp, i32p, C.c_int, i32p, i32p, vp, i32p]
     lib.rpe_match_l2.restype = C.c_int
+    lib.rpe_estimate_stream.argtypes = [vp, vp, C.c_int, vp, vp, vp, i32p, i32p, i32p]; lib.rpe_estimate_stream.restype = C.c_int
+    lib.rpe_enqueue_stream_device.argtypes = [vp, vp, C.c_int, vp]; lib.rpe_enqueue_stream_device.restype = C.c_int
     _lib = lib
     return lib
 
@@ -172,6 +175,19 @@ class Engine:
         R, t, inl, nm, st = self._outs(B)
         self._chk(self.lib.rpe_estimate_batch(self.h, _p(imgs1), _p(imgs2), B, _p(K), _p(R), _p(t), _p(inl), _p(nm), _p(st)))
         return R, t, inl, nm, st
+
+    def estimate_stream(self, frames, K):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        F = frames.shape[0]
+        assert frames.shape == (F, self.height, self.width)
+        K = np.ascontiguousarray(K, np.float64)
+        R, t, inl, nm, st = self._outs(F - 1)
+        self._chk(self.lib.rpe_estimate_stream(self.h, _p(frames), F, _p(K), _p(R), _p(t), _p(inl), _p(nm), _p(st)))
+        return R, t, inl, nm, st
+
+    def enqueue_stream_device(self, d_frames, F, K):
+        K = np.ascontiguousarray(K, np.float64)
+        self._chk(self.lib.rpe_enqueue_stream_device(self.h, d_frames, F, _p(K)))
 
     def estimate_batch_device(self, d_imgs1, d_imgs2, B, K):
         K = np.ascontiguousarray(K, np.float64)

@@ -776,6 +776,6 @@ void rpe_launch_pose(rpe_handle *h, int B, bool fused)
 {
     hipLaunchKernelGGL(recover_pose_kernel, dim3(B), dim3(256), 0, h->stream,
                        h->d_E, h->d_pts1, h->d_pts2, h->d_m_n, fused ? h->d_found : (const int *)nullptr,
-                       fused ? h->d_kp_count : (const int *)nullptr, B, h->d_K,
+                       fused ? h->d_kp_count : (const int *)nullptr, h->img2_base ? h->img2_base : B, h->d_K,
                        h->d_R, h->d_t, h->d_inliers, h->d_status, h->cfg.max_matches);
 }

@@ -116,7 +116,7 @@ void rpe_launch_match(rpe_handle *h, int B)
     const int kcap = h->lay.kcap;
     size_t lds = (size_t)QTILE * 32 + (size_t)kcap * 4;
     hipLaunchKernelGGL(match_hamming_kernel, dim3(B), dim3(256), lds, h->stream,
-                       h->d_desc, h->d_kp_count, h->d_kp_pt, B, kcap, h->cfg.max_matches,
+                       h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches,
                        h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
 }
 
@@ -244,6 +244,6 @@ void rpe_launch_match_l2(rpe_handle *h, int B)
     const int kcap = h->lay.kcap;
     size_t lds = (size_t)L2_QTILE * 128 + (size_t)L2_QTILE * 4 + (size_t)kcap * 8;
     hipLaunchKernelGGL(match_l2_kernel, dim3(B), dim3(256), lds, h->stream,
-                       h->d_desc, h->d_kp_count, h->d_kp_pt, B, kcap, h->cfg.max_matches,
+                       h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches,
                        h->d_m_q, h->d_m_t, (float *)h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
 }

@@ -445,6 +445,60 @@ extern "C" int rpe_enqueue_batch_device(rpe_handle *h, const uint8_t *d_imgs1, c
     return RPE_OK;
 }
 
+// Consecutive-frame stream (reference batch_processor.py:71-109): F frames -> F-1
+// pairs (i, i+1).  Features are extracted ONCE per frame (the reference extracts every interior
+// frame twice, batch_processor.py:79,92); pair p reads image slots p and p+1.
+extern "C" int rpe_enqueue_stream_device(rpe_handle *h, const uint8_t *d_frames, int F, const double K[9])
+{
+    if (!h || !d_frames || !K || F < 2) return RPE_ERR_INVALID;
+    if (F > h->n_img_cap || F - 1 > h->cfg.max_batch) { h->err = "stream longer than the handle capacity (frames <= 2*max_batch, pairs <= max_batch)"; return RPE_ERR_CAPACITY; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = set_K(h, K);
+    if (rc) return rc;
+    h->img2_base = 1;
+    if (h->cfg.feature_method == RPE_FEATURE_SIFT) {
+        MARK(h, RPE_STAGE_PYRAMID);
+        if ((rc = rpe_sift_run(h, d_frames, d_frames, F, 0)) != RPE_OK) return rc;
+        for (int s = RPE_STAGE_FAST; s <= RPE_STAGE_MATCH; ++s) MARK(h, s);
+        rpe_launch_match_l2(h, F - 1);
+    } else {
+        if ((rc = run_orb(h, d_frames, d_frames, F, 0)) != RPE_OK) return rc;
+        rpe_launch_match(h, F - 1);
+    }
+    MARK(h, RPE_STAGE_RANSAC);
+    rpe_launch_ransac(h, F - 1, false);
+    MARK(h, RPE_STAGE_POSE);
+    rpe_launch_pose(h, F - 1, true);
+    h->img2_base = 0;
+    if (h->profiling) { hipEventRecord(h->ev[RPE_STAGE_COUNT], h->stream); h->ev_valid = true; }
+    HIPCHK(h, hipGetLastError());
+    return RPE_OK;
+}
+
+extern "C" int rpe_estimate_stream(rpe_handle *h, const uint8_t *h_frames, int F, const double K[9],
+                                   double *R, double *t, int32_t *inliers, int32_t *n_matches, int32_t *status)
+{
+    if (!h || !h_frames || F < 2) return RPE_ERR_INVALID;
+    if (F > h->n_img_cap || F - 1 > h->cfg.max_batch) { h->err = "stream longer than the handle capacity (frames <= 2*max_batch, pairs <= max_batch)"; return RPE_ERR_CAPACITY; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t img = (size_t)h->cfg.width * h->cfg.height;
+    // staging: frames are spread over the two staging buffers only if they do not fit the first
+    if ((size_t)F <= (size_t)h->cfg.max_batch) {
+        HIPCHK(h, hipMemcpyAsync(h->d_stage1, h_frames, img * F, hipMemcpyHostToDevice, h->stream));
+        int rc = rpe_enqueue_stream_device(h, h->d_stage1, F, K);
+        if (rc) return rc;
+    } else {
+        void *tmp = nullptr;
+        HIPCHK(h, hipMalloc(&tmp, img * F));
+        HIPCHK(h, hipMemcpyAsync(tmp, h_frames, img * F, hipMemcpyHostToDevice, h->stream));
+        int rc = rpe_enqueue_stream_device(h, (const uint8_t *)tmp, F, K);
+        hipStreamSynchronize(h->stream);
+        hipFree(tmp);
+        if (rc) return rc;
+    }
+    return rpe_fetch_results(h, F - 1, R, t, inliers, n_matches, status);
+}
+
 extern "C" int rpe_fetch_results(rpe_handle *h, int B, double *R, double *t, int32_t *inliers, int32_t *n_matches, int32_t *status)
 {
     if (!h || B < 1 || B > h->cfg.max_batch) return RPE_ERR_INVALID;

@@ -57,6 +57,7 @@ struct RpeSiftState;
 struct rpe_handle {
     rpe_config cfg;
     RpeSiftState *sift = nullptr;             // SIFT workspace (feature_method == RPE_FEATURE_SIFT)
+    int img2_base = 0;                        // 0: pair p = slots (p, B+p); 1: stream, pair p = slots (p, p+1)
     int desc_bytes = 32;                      // 32 (rBRIEF) or 128 (SIFT, stored as u8)
     std::string err;
     hipStream_t stream = nullptr;

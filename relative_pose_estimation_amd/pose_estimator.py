@@ -108,6 +108,17 @@ class PoseEstimator:
         self._last_n_matches = nm
         return R, t, inl, st
 
+    def estimate_sequence(self, frames):
+        """Relative poses of consecutive frames (frame i -> i+1): the pair loop of the reference's
+        BatchProcessor.process_sequence (batch_processor.py:71-109) with features extracted once
+        per frame.  Returns (R[F-1,3,3], t[F-1,3,1], inliers[F-1], status[F-1])."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        F, H, W = frames.shape
+        eng = self._engine(H, W, F - 1)
+        R, t, inl, nm, st = eng.estimate_stream(frames, self.K)
+        self._last_n_matches = nm
+        return R, t, inl, st
+
     def estimate(self, img1, img2, R_prev=None):
         img1 = self._gray(img1); img2 = self._gray(img2)
         eng = self._engine(img1.shape[0], img1.shape[1], 1)

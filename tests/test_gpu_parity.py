@@ -292,3 +292,20 @@ def test_sift_end_to_end(capi, eng_sift, oracle):
         no, Ro, to = oracle.recover_pose(E, p1, p2, K)
         assert st[n] == 0 and nm[n] == len(q) and inl[n] == no
         assert np.linalg.norm(R[n] - Ro) <= TOL_RT and np.linalg.norm(t[n] - to) <= TOL_RT
+
+
+def test_stream_equals_pairwise(capi, oracle, K_vga):
+    """consecutive-frame stream (reference batch_processor.py:71-109): F-1 poses, each equal to the
+    pairwise estimate of (frame i, frame i+1); features extracted once per frame"""
+    from relative_pose_estimation_amd import synthetic, PoseEstimator
+    i1, i2, _, _ = synthetic.make_batch(3, K_vga, cfg=8)
+    frames = np.stack([i1[0], i2[0], i1[1], i2[1], i1[2]])
+    pe = PoseEstimator(K_vga, nfeatures=1000, max_batch=4)
+    R, t, inl, st = pe.estimate_sequence(frames)
+    assert R.shape == (4, 3, 3)
+    for i in range(4):
+        r = oracle.estimate_pose(frames[i], frames[i + 1], K_vga, 1000, 500)
+        assert st[i] == r["status"]
+        if r["status"] == 0:
+            assert np.array_equal(R[i], r["R"]) and np.array_equal(t[i], r["t"]) and inl[i] == r["inliers"]
+    pe.close()
