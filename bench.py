@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3],
                     help="BASELINE configs[]: 2 = 1024 VGA pairs ORB(1000)+Hamming (the metric's config, default); "
                          "3 = 1920x1080 pairs SIFT(2048)+L2, processed in sub-batches")
+    ap.add_argument("--stream", action="store_true",
+                    help="BASELINE configs[4] stand-in: consecutive-frame stream (batch+1 frames -> batch pairs), features once per frame")
     ap.add_argument("--sub-batch", type=int, default=0, help="pairs per enqueue (config 3 default 32: 1.1 GB of pyramid per pair)")
     ap.add_argument("--streams", type=int, default=1, help="split the batch over S engine handles (S HIP streams) so latency-bound stages overlap")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of the N>1 path)")
@@ -143,12 +145,15 @@ def main():
     cores = os.cpu_count() or 1
     workers = args.gen_workers or max(1, min(16, cores // max(1, world)))
     # global pair index space: rank r owns pairs [r*B, (r+1)*B) (weak scaling)
-    cache = f"{args.data_cache}.r{rank}.npz" if args.data_cache else ""
+    if args.stream:
+        frames, Rgt, tgt = synthetic.make_stream(B + 1, K, W, H, seed=5_000_011 + rank, workers=workers)
+        i1, i2 = frames[:-1], frames[1:]
+    cache = f"{args.data_cache}.r{rank}.npz" if args.data_cache and not args.stream else ""
     if cache and os.path.exists(cache):
         z = np.load(cache)
         i1, i2, Rgt, tgt = z["i1"], z["i2"], z["R"], z["t"]
         assert i1.shape == (B, H, W), "data cache does not match the requested workload"
-    else:
+    elif not args.stream:
         i1, i2, Rgt, tgt = synthetic.make_batch(B, K, W, H, cfg=2, first=rank * B, workers=workers)
         if cache:
             np.savez(cache, i1=i1, i2=i2, R=Rgt, t=tgt)
@@ -165,7 +170,12 @@ def main():
                          feature_method=fm, norm_type=nt)
             for lo, hi in bounds]
     eng = engs[0]
-    dbuf = [(e.upload(i1[lo:hi]), e.upload(i2[lo:hi])) for e, (lo, hi) in zip(engs, bounds)]   # inputs resident in HBM
+    if args.stream:
+        assert S == 1 and sub >= B, "--stream uses one handle and one launch group"
+        d_frames = engs[0].upload(frames)
+        dbuf = [(d_frames, d_frames)]
+    else:
+        dbuf = [(e.upload(i1[lo:hi]), e.upload(i2[lo:hi])) for e, (lo, hi) in zip(engs, bounds)]   # inputs resident in HBM
     for e in engs:
         e.set_profiling(True)
 
@@ -180,7 +190,10 @@ def main():
     sub_acc = {}
 
     def step():
-        if sub >= B:
+        if args.stream:
+            engs[0].enqueue_stream_device(dbuf[0][0], B + 1, K)
+            parts = [engs[0].fetch_results(B)]
+        elif sub >= B:
             for e, (a, b), (lo, hi) in zip(engs, dbuf, bounds):
                 e.enqueue_batch_device(a, b, hi - lo, K)
             parts = [e.fetch_results(hi - lo) for e, (lo, hi) in zip(engs, bounds)]
@@ -255,7 +268,8 @@ def main():
             "dtype": "u8/i32 (ORB, Hamming) + f64 (RANSAC, pose)",
             "data": "synthetic",
             "config": {"workload": (f"{B} {W}x{H} pairs per GPU, ORB({args.nfeatures}kp)+BF-Hamming crossCheck top-{args.max_matches}"
-                                    "+5pt-RANSAC(0.999,1px)+recoverPose (BASELINE configs[1])") if method == "ORB" else
+                                    "+5pt-RANSAC(0.999,1px)+recoverPose (BASELINE configs[1])" +
+                                    (f"; consecutive-frame stream of {B + 1} frames, features once per frame (configs[4] stand-in)" if args.stream else "")) if method == "ORB" else
                                    (f"{B} {W}x{H} pairs per GPU in sub-batches of {sub}, SIFT(cap {args.nfeatures})+BF-L2 crossCheck "
                                     f"top-{args.max_matches}+5pt-RANSAC+recoverPose (BASELINE configs[2] shape, reduced pair count)"),
                        "pairs_per_gpu": B, "global_pairs": world * B, "streams_per_gpu": S, "pairs_per_launch": Bl, "sharding": f"pairs x{world}, RCCL all-gather of 128-B pose records"},

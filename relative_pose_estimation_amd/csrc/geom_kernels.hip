@@ -209,15 +209,12 @@ __device__ static int poly_real_roots10(const double (&c)[11], double *roots)
 // mx: this lane's 10x20 elimination matrix in LDS, element (i,j) at mx[(i*20+j)*64]
 // (lane-interleaved: conflict-free ds_read/write_b64, no scratch round trips)
 #define MX(i, j) mx[((i) * 20 + (j)) * 64]
-__device__ static int five_point_dev(const double *x1, const double *x2, double *E_out, double *mx)
+// Part A of the solver (LDS-heavy): null space, constraint matrix, Gauss-Jordan, det B(z).
+// Writes the hypothesis record rec[k*64] (k = 0..86): c10[11], Bx[12], By[12], B1[15], Eb[36], degree n;
+// returns 0 when the elimination is singular.
+#define HYP_DOUBLES 88
+__device__ static int five_point_poly(const double *x1, const double *x2, double *mx, double *rec)
 {
-#ifdef RPE_STAMPS
-    long long st_[8]; int sti_ = 0;
-#define STAMP() st_[sti_++] = clock64()
-#else
-#define STAMP()
-#endif
-    STAMP();
     double A[9][5];
     for (int k = 0; k < 5; ++k) {
         double a = x1[2 * k], b = x1[2 * k + 1], c = x2[2 * k], d = x2[2 * k + 1];
@@ -259,7 +256,6 @@ __device__ static int five_point_dev(const double *x1, const double *x2, double 
     }
     double El[9][4];
     for (int e = 0; e < 9; ++e) for (int m = 0; m < 4; ++m) El[e][m] = Eb[m][e];
-    STAMP();
     double EEt[3][3][10];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int q = 0; q < 10; ++q) EEt[i][j][q] = 0.;
     for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) {
@@ -290,7 +286,6 @@ __device__ static int five_point_dev(const double *x1, const double *x2, double 
         ql_acc(row, m2, El[2], 1.);
         for (int q = 0; q < 20; ++q) MX(9, q) = row[q];
     }
-    STAMP();
     for (int c = 0; c < 10; ++c) {
         double col[10];
 #pragma unroll
@@ -325,7 +320,6 @@ __device__ static int five_point_dev(const double *x1, const double *x2, double 
             for (int j = 0; j < 20; ++j) MX(r, j) = row[j];
         }
     }
-    STAMP();
     double Bx[3][4], By[3][4], B1[3][5];
     for (int i = 0; i < 3; ++i) {
         double e[10], f[10];
@@ -346,10 +340,31 @@ __device__ static int five_point_dev(const double *x1, const double *x2, double 
     }
     int n = 10;
     for (; n > 1; --n) if (fabs(c10[n]) > DBL_EPSILON) break;
+    for (int i = 0; i < 11; ++i) rec[i * 64] = c10[i];
+    for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k < 4; ++k) { rec[(11 + i * 4 + k) * 64] = Bx[i][k]; rec[(23 + i * 4 + k) * 64] = By[i][k]; }
+        for (int k = 0; k < 5; ++k) rec[(35 + i * 5 + k) * 64] = B1[i][k];
+    }
+    for (int m = 0; m < 4; ++m) for (int e = 0; e < 9; ++e) rec[(50 + m * 9 + e) * 64] = Eb[m][e];
+    rec[86 * 64] = (double)n;
+    return 1;
+}
+
+// Part B (register-resident, no LDS): real roots of the degree-10 polynomial, back-substitution.
+__device__ static int five_point_roots(const double *rec, double *E_out)
+{
+    double c10[11];
+    for (int i = 0; i < 11; ++i) c10[i] = rec[i * 64];
+    const int n = (int)rec[86 * 64];
+    double Bx[3][4], By[3][4], B1[3][5];
     double roots[10];
-    STAMP();
     int nroots = (n == 10) ? poly_real_roots10(c10, roots) : poly_real_roots_generic(c10, n, roots);
-    STAMP();
+    if (nroots > 0) {
+        for (int i = 0; i < 3; ++i) {
+            for (int k = 0; k < 4; ++k) { Bx[i][k] = rec[(11 + i * 4 + k) * 64]; By[i][k] = rec[(23 + i * 4 + k) * 64]; }
+            for (int k = 0; k < 5; ++k) B1[i][k] = rec[(35 + i * 5 + k) * 64];
+        }
+    }
     int count = 0;
     for (int ri = 0; ri < nroots && count < 10; ++ri) {
         double z = roots[ri];
@@ -375,7 +390,7 @@ __device__ static int five_point_dev(const double *x1, const double *x2, double 
         double x = xv0 / xv2, y = xv1 / xv2;
         double Ev[9], nrm = 0.;
         for (int e = 0; e < 9; ++e) {
-            Ev[e] = ((Eb[0][e] * x + Eb[1][e] * y) + Eb[2][e] * z) + Eb[3][e];
+            Ev[e] = ((rec[(50 + e) * 64] * x + rec[(59 + e) * 64] * y) + rec[(68 + e) * 64] * z) + rec[(77 + e) * 64];
             nrm += Ev[e] * Ev[e];
         }
         nrm = sqrt(nrm);
@@ -383,11 +398,6 @@ __device__ static int five_point_dev(const double *x1, const double *x2, double 
         for (int e = 0; e < 9; ++e) E_out[count * 9 + e] = Ev[e] / nrm;
         ++count;
     }
-    STAMP();
-#ifdef RPE_STAMPS
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        printf("[stamps] null %lld build %lld gj %lld poly %lld roots %lld back %lld (nroots %d)\n", st_[1]-st_[0], st_[2]-st_[1], st_[3]-st_[2], st_[4]-st_[3], st_[5]-st_[4], st_[6]-st_[5], nroots);
-#endif
     return count;
 }
 
@@ -418,22 +428,20 @@ __global__ __launch_bounds__(256) void ransac_prepare_kernel(const float2 *__res
 }
 
 // ------------------------------------------------------------------ solve
-__global__ __launch_bounds__(64) void ransac_solve_kernel(const double2 *__restrict__ n1, const double2 *__restrict__ n2,
-                                                           const RpeRansacState *__restrict__ st,
-                                                           const unsigned short *__restrict__ subsets,
-                                                           double *__restrict__ models, int *__restrict__ nmodels,
-                                                           int max_matches, int max_iters, int n_pairs)
+// A: one wave per (pair, 64 iterations); 100 KB of LDS per wave => one wave per CU
+__global__ __launch_bounds__(64) void ransac_poly_kernel(const double2 *__restrict__ n1, const double2 *__restrict__ n2,
+                                                          const RpeRansacState *__restrict__ st,
+                                                          const unsigned short *__restrict__ subsets,
+                                                          double *__restrict__ hyp, int *__restrict__ nmodels,
+                                                          int max_matches, int max_iters)
 {
-    // one wave = (64 / RPE_RANSAC_CHUNK) pairs x RPE_RANSAC_CHUNK consecutive iterations
     __shared__ double s_mx[200 * 64];
-    const int sub = threadIdx.x / RPE_RANSAC_CHUNK, lane = threadIdx.x % RPE_RANSAC_CHUNK;
-    const int pair = blockIdx.x * (64 / RPE_RANSAC_CHUNK) + sub;
-    if (pair >= n_pairs) return;
+    const int pair = blockIdx.x, wv = blockIdx.y, lane = threadIdx.x;
     const RpeRansacState s = st[pair];
     if (s.done) return;
-    const int it = s.next_iter + lane;
-    const long long slot = (long long)pair * RPE_RANSAC_CHUNK + lane;
-    int nm = 0;
+    const int it = s.next_iter + wv * 64 + lane;
+    const long long slot = (long long)pair * RPE_RANSAC_MAXCHUNK + wv * 64 + lane;
+    int ok = 0;
     const bool all5 = (s.M == 5);
     if (it < s.niters && (!all5 || it == 0)) {
         double x1[10], x2[10];
@@ -443,8 +451,26 @@ __global__ __launch_bounds__(64) void ransac_solve_kernel(const double2 *__restr
             double2 a = n1[(long long)pair * max_matches + v], b = n2[(long long)pair * max_matches + v];
             x1[2 * k] = a.x; x1[2 * k + 1] = a.y; x2[2 * k] = b.x; x2[2 * k + 1] = b.y;
         }
+        ok = five_point_poly(x1, x2, s_mx + lane, hyp + ((long long)pair * (RPE_RANSAC_MAXCHUNK / 64) + wv) * HYP_DOUBLES * 64 + lane);
+    }
+    nmodels[slot] = ok ? -1 : 0;          // -1: record valid, roots pending
+}
+
+// B: roots + back-substitution; no LDS, moderate registers => many waves per CU hide the f64 latency
+__global__ __launch_bounds__(256) void ransac_roots_kernel(const RpeRansacState *__restrict__ st, const double *__restrict__ hyp,
+                                                            double *__restrict__ models, int *__restrict__ nmodels, int n_pairs,
+                                                            int waves_per_pair)
+{
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int pair = gw / waves_per_pair, wv = gw - pair * waves_per_pair;
+    if (pair >= n_pairs) return;
+    const RpeRansacState s = st[pair];
+    if (s.done || s.next_iter + wv * 64 >= s.niters) return;
+    const long long slot = (long long)pair * RPE_RANSAC_MAXCHUNK + wv * 64 + lane;
+    int nm = 0;
+    if (nmodels[slot] == -1) {
         double E[90];
-        nm = five_point_dev(x1, x2, E, s_mx + threadIdx.x);
+        nm = five_point_roots(hyp + ((long long)pair * (RPE_RANSAC_MAXCHUNK / 64) + wv) * HYP_DOUBLES * 64 + lane, E);
         double *dst = models + slot * (RPE_MAX_MODELS * 9);
         for (int e = 0; e < nm * 9; ++e) dst[e] = E[e];
     }
@@ -482,11 +508,11 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const double2 *__rest
                                                             const int *__restrict__ nmodels, const double *__restrict__ K,
                                                             const double *__restrict__ nit_denom, const int *__restrict__ nit_round,
                                                             double nit_num, double threshold, double *__restrict__ E_out,
-                                                            int *__restrict__ found, int max_matches)
+                                                            int *__restrict__ found, int max_matches, int chunk)
 {
     extern __shared__ double2 s_pts[];              // [2][M]
-    __shared__ int s_counts[RPE_RANSAC_CHUNK * RPE_MAX_MODELS];
-    __shared__ int s_nm[RPE_RANSAC_CHUNK];
+    __shared__ int s_counts[RPE_RANSAC_MAXCHUNK * RPE_MAX_MODELS];
+    __shared__ int s_nm[RPE_RANSAC_MAXCHUNK];
     const int pair = blockIdx.x, tid = threadIdx.x;
     RpeRansacState s = st[pair];
     if (s.done) return;
@@ -496,18 +522,18 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const double2 *__rest
         sp1[i] = n1[(long long)pair * max_matches + i];
         sp2[i] = n2[(long long)pair * max_matches + i];
     }
-    for (int i = tid; i < RPE_RANSAC_CHUNK * RPE_MAX_MODELS; i += 256) s_counts[i] = 0;
-    if (tid < RPE_RANSAC_CHUNK) s_nm[tid] = nmodels[(long long)pair * RPE_RANSAC_CHUNK + tid];
+    const int kmax = min(chunk, s.niters - s.next_iter);
+    for (int i = tid; i < kmax * RPE_MAX_MODELS; i += 256) s_counts[i] = 0;
+    for (int i = tid; i < kmax; i += 256) s_nm[i] = nmodels[(long long)pair * RPE_RANSAC_MAXCHUNK + i];
     __syncthreads();
     const double fx = K[0], fy = K[4];
     const double thr = threshold / ((fx + fy) / 2);
     const float thr2 = (float)(thr * thr);
-    const int kmax = min(RPE_RANSAC_CHUNK, s.niters - s.next_iter);
     if (M > 5) {
         for (int k = 0; k < kmax; ++k) {
             const int nm = s_nm[k];
             for (int m = 0; m < nm; ++m) {
-                const double *Eg = models + (((long long)pair * RPE_RANSAC_CHUNK + k) * RPE_MAX_MODELS + m) * 9;
+                const double *Eg = models + (((long long)pair * RPE_RANSAC_MAXCHUNK + k) * RPE_MAX_MODELS + m) * 9;
                 double E[9];
 #pragma unroll
                 for (int e = 0; e < 9; ++e) E[e] = Eg[e];
@@ -545,10 +571,10 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const double2 *__rest
                     }
                 }
             }
-            s.next_iter += RPE_RANSAC_CHUNK;
+            s.next_iter += chunk;
         }
         if (bk >= 0) {
-            const double *Eg = models + (((long long)pair * RPE_RANSAC_CHUNK + bk) * RPE_MAX_MODELS + bm) * 9;
+            const double *Eg = models + (((long long)pair * RPE_RANSAC_MAXCHUNK + bk) * RPE_MAX_MODELS + bm) * 9;
             for (int e = 0; e < 9; ++e) { s.E[e] = Eg[e]; E_out[pair * 9 + e] = Eg[e]; }
         }
         s.best_count = best; s.niters = niters;
@@ -588,15 +614,22 @@ void rpe_launch_ransac(rpe_handle *h, int B, bool want_mask)
     double2 *n1 = h->d_n1, *n2 = h->d_n2;
     hipLaunchKernelGGL(ransac_prepare_kernel, dim3((mm + 255) / 256, B), dim3(256), 0, h->stream,
                        h->d_pts1, h->d_pts2, h->d_m_n, h->d_K, n1, n2, h->d_rstate, h->d_found, mm, it);
-    const int nchunks = (it + RPE_RANSAC_CHUNK - 1) / RPE_RANSAC_CHUNK;
+    // chunk schedule 64, 64, 128, 256, 512, 512, ...: most pairs stop inside the first 64 iterations;
+    // launches are bound by single-wave latency, so long-running pairs get more waves per launch
     const size_t lds = sizeof(double2) * 2 * (size_t)mm;
-    for (int c = 0; c < nchunks; ++c) {
-        const int ppw = 64 / RPE_RANSAC_CHUNK;
-        hipLaunchKernelGGL(ransac_solve_kernel, dim3((B + ppw - 1) / ppw), dim3(64), 0, h->stream,
-                           n1, n2, h->d_rstate, h->d_subsets, h->d_models, h->d_nmodels, mm, it, B);
+    int done_iters = 0, chunk = 64, nlaunch = 0;
+    while (done_iters < it) {
+        const int wpp = chunk / 64;
+        hipLaunchKernelGGL(ransac_poly_kernel, dim3(B, wpp), dim3(64), 0, h->stream,
+                           n1, n2, h->d_rstate, h->d_subsets, h->d_hyp, h->d_nmodels, mm, it);
+        hipLaunchKernelGGL(ransac_roots_kernel, dim3((B * wpp + 3) / 4), dim3(256), 0, h->stream,
+                           (const RpeRansacState *)h->d_rstate, (const double *)h->d_hyp, h->d_models, h->d_nmodels, B, wpp);
         hipLaunchKernelGGL(ransac_score_kernel, dim3(B), dim3(256), lds, h->stream,
                            n1, n2, h->d_rstate, h->d_models, h->d_nmodels, h->d_K, h->d_nit_denom, h->d_nit_round,
-                           h->nit_num, h->cfg.ransac_threshold, h->d_E, h->d_found, mm);
+                           h->nit_num, h->cfg.ransac_threshold, h->d_E, h->d_found, mm, chunk);
+        done_iters += chunk;
+        ++nlaunch;
+        if (nlaunch >= 2 && chunk < RPE_RANSAC_MAXCHUNK) chunk *= 2;
     }
     if (want_mask)
         hipLaunchKernelGGL(ransac_mask_kernel, dim3(B), dim3(256), 0, h->stream,

@@ -10,7 +10,8 @@
 #define RPE_NLEVELS RPE_ORB_LEVELS
 #define RPE_EDGE 31            // ORB edgeThreshold (cv2 default; pose_estimator.py:85-91 leaves it)
 #define RPE_HALF_PATCH 15      // patchSize 31
-#define RPE_RANSAC_CHUNK 64    // RANSAC iterations evaluated per launch group (one solver wave per pair)
+#define RPE_RANSAC_CHUNK 64    // solver wave granularity: 64 RANSAC iterations per wave
+#define RPE_RANSAC_MAXCHUNK 512 // largest number of iterations evaluated per launch group (8 waves per pair)
 #define RPE_MAX_MODELS 10
 
 // ---- HBM layout of one image's pyramid-shaped buffers ---------------------
@@ -92,6 +93,7 @@ struct rpe_handle {
     RpeRansacState *d_rstate = nullptr;
     double2 *d_n1 = nullptr, *d_n2 = nullptr;   // K-normalised matched points [pair][max_matches]
     int *d_found = nullptr;                   // [pair]
+    double *d_hyp = nullptr;              // [pair][88][64] per-hypothesis record between the two solver kernels
     double *d_models = nullptr;           // [pair][CHUNK][10][9]
     int *d_nmodels = nullptr;             // [pair][CHUNK]
     uint8_t *d_mask = nullptr;            // [pair][max_matches]

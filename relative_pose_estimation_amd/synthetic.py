@@ -105,3 +105,39 @@ def make_batch(n, K, W=640, H=480, cfg=2, first=0, workers=1):
     i1 = np.stack([o[0] for o in out]); i2 = np.stack([o[1] for o in out])
     R = np.stack([o[2] for o in out]); t = np.stack([o[3] for o in out])
     return i1, i2, R, t
+
+
+def _stream_job(args):
+    K, R, t, W, H, seed, focal, nseed = args
+    rng = np.random.default_rng(int(nseed))
+    return _finish(_render(K, R, t, W, H, int(seed), focal), rng)
+
+
+def make_stream(n_frames, K, W=640, H=480, seed=5_000_011, max_angle_deg=2.0, step=0.12, workers=1):
+    """One camera moving through ONE scene (KITTI-like consecutive-frame stream, BASELINE config 5
+    stand-in): frames [n,H,W], and the ground-truth relative pose of every consecutive pair
+    (X_{i+1} = R_rel X_i + t_rel, |t_rel| = 1).  The camera random-walks with small rotations and
+    a bounded position so that the scene stays in view."""
+    rng = np.random.default_rng(int(seed))
+    K = np.asarray(K, np.float64)
+    focal = 0.5 * (K[0, 0] + K[1, 1])
+    Rs, ts = [np.eye(3)], [np.zeros(3)]
+    for i in range(1, n_frames):
+        Rr = _rot(*rng.uniform(-max_angle_deg, max_angle_deg, 3))
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        c_prev = -Rs[-1].T @ ts[-1]                       # camera centre in the scene frame
+        if np.linalg.norm(c_prev) > 1.0:                  # drift back towards the origin
+            d = -Rs[-1] @ (c_prev / np.linalg.norm(c_prev))
+        tr = d * step
+        Rs.append(Rr @ Rs[-1]); ts.append(Rr @ ts[-1] + tr)
+    jobs = [(K, Rs[i], ts[i], W, H, seed, focal, seed * 31 + i) for i in range(n_frames)]
+    if workers > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            frames = pool.map(_stream_job, jobs, chunksize=max(1, n_frames // (workers * 4)))
+    else:
+        frames = [_stream_job(j) for j in jobs]
+    R_rel = np.stack([Rs[i + 1] @ Rs[i].T for i in range(n_frames - 1)])
+    t_rel = np.stack([(ts[i + 1] - Rs[i + 1] @ Rs[i].T @ ts[i]) for i in range(n_frames - 1)])
+    t_rel = t_rel / np.linalg.norm(t_rel, axis=1, keepdims=True)
+    return np.stack(frames), R_rel, t_rel.reshape(-1, 3, 1)
