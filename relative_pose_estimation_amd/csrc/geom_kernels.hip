@@ -503,86 +503,100 @@ __device__ __forceinline__ int update_niters(const double *nit_denom, const int 
 }
 
 // ------------------------------------------------------------------ score
+// One workgroup per (pair, group of 64 iterations).  The K-normalised matches sit in LDS; each of
+// the 4 waves scores a different model (lanes stride over the matches, Sampson error f64 -> f32
+// compare, wave-shuffle popcount), so there is no cross-wave reduction.  Counts go to HBM.
 __global__ __launch_bounds__(256) void ransac_score_kernel(const double2 *__restrict__ n1, const double2 *__restrict__ n2,
-                                                            RpeRansacState *__restrict__ st, const double *__restrict__ models,
+                                                            const RpeRansacState *__restrict__ st, const double *__restrict__ models,
                                                             const int *__restrict__ nmodels, const double *__restrict__ K,
-                                                            const double *__restrict__ nit_denom, const int *__restrict__ nit_round,
-                                                            double nit_num, double threshold, double *__restrict__ E_out,
-                                                            int *__restrict__ found, int max_matches, int chunk)
+                                                            double threshold, int *__restrict__ counts, int max_matches)
 {
     extern __shared__ double2 s_pts[];              // [2][M]
-    __shared__ int s_counts[RPE_RANSAC_MAXCHUNK * RPE_MAX_MODELS];
-    __shared__ int s_nm[RPE_RANSAC_MAXCHUNK];
-    const int pair = blockIdx.x, tid = threadIdx.x;
-    RpeRansacState s = st[pair];
-    if (s.done) return;
+    __shared__ int s_nm[64], s_first[65];
+    const int pair = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const RpeRansacState s = st[pair];
+    if (s.done || s.M <= 5 || s.next_iter + grp * 64 >= s.niters) return;
     const int M = s.M;
     double2 *sp1 = s_pts, *sp2 = s_pts + max_matches;
     for (int i = tid; i < M; i += 256) {
         sp1[i] = n1[(long long)pair * max_matches + i];
         sp2[i] = n2[(long long)pair * max_matches + i];
     }
-    const int kmax = min(chunk, s.niters - s.next_iter);
-    for (int i = tid; i < kmax * RPE_MAX_MODELS; i += 256) s_counts[i] = 0;
-    for (int i = tid; i < kmax; i += 256) s_nm[i] = nmodels[(long long)pair * RPE_RANSAC_MAXCHUNK + i];
+    const long long slot0 = (long long)pair * RPE_RANSAC_MAXCHUNK + grp * 64;
+    if (tid < 64) s_nm[tid] = nmodels[slot0 + tid];
+    __syncthreads();
+    if (tid == 0) { int acc = 0; for (int k = 0; k < 64; ++k) { s_first[k] = acc; acc += s_nm[k]; } s_first[64] = acc; }
     __syncthreads();
     const double fx = K[0], fy = K[4];
     const double thr = threshold / ((fx + fy) / 2);
     const float thr2 = (float)(thr * thr);
-    if (M > 5) {
+    const int total = s_first[64];
+    int k = 0;
+    for (int j = wv; j < total; j += 4) {            // j-th model of this group, flattened (iteration-major)
+        while (s_first[k + 1] <= j) ++k;
+        const int m = j - s_first[k];
+        const double *Eg = models + ((slot0 + k) * RPE_MAX_MODELS + m) * 9;
+        double E[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) E[e] = Eg[e];
+        int cnt = 0;
+        for (int i = lane; i < M; i += 64) {
+            double2 a = sp1[i], b = sp2[i];
+            cnt += sampson_inlier(E, a.x, a.y, b.x, b.y, thr2);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (lane == 0) counts[(slot0 + k) * RPE_MAX_MODELS + m] = cnt;
+    }
+}
+
+// Sequential replay of OpenCV's update rule (ptsetreg.cpp) over the counts of one chunk:
+// "strictly more inliers wins", niters shrinks through RANSACUpdateNumIters, the loop stops at niters.
+__global__ __launch_bounds__(64) void ransac_update_kernel(RpeRansacState *__restrict__ st, const double *__restrict__ models,
+                                                            const int *__restrict__ nmodels, const int *__restrict__ counts,
+                                                            const double *__restrict__ nit_denom, const int *__restrict__ nit_round,
+                                                            double nit_num, double *__restrict__ E_out, int *__restrict__ found,
+                                                            int chunk, int n_pairs)
+{
+    const int pair = blockIdx.x * 64 + threadIdx.x;
+    if (pair >= n_pairs) return;
+    RpeRansacState s = st[pair];
+    if (s.done) return;
+    const int M = s.M;
+    const long long slot0 = (long long)pair * RPE_RANSAC_MAXCHUNK;
+    int best = s.best_count, niters = s.niters, bk = -1, bm = -1;
+    if (M == 5) {
+        // ptsetreg.cpp: count == modelPoints -> runKernel on all points, first model kept
+        if (nmodels[slot0] > 0) { best = 5; bk = 0; bm = 0; s.best_iter = 0; s.best_model = 0; }
+        niters = 1;
+        s.next_iter = 1;
+        s.iters_run = 1;
+    } else {
+        const int kmax = min(chunk, s.niters - s.next_iter);
         for (int k = 0; k < kmax; ++k) {
-            const int nm = s_nm[k];
+            const int it = s.next_iter + k;
+            if (it >= niters) break;
+            s.iters_run = it + 1;
+            const int nm = nmodels[slot0 + k];
             for (int m = 0; m < nm; ++m) {
-                const double *Eg = models + (((long long)pair * RPE_RANSAC_MAXCHUNK + k) * RPE_MAX_MODELS + m) * 9;
-                double E[9];
-#pragma unroll
-                for (int e = 0; e < 9; ++e) E[e] = Eg[e];
-                int cnt = 0;
-                for (int i = tid; i < M; i += 256) {
-                    double2 a = sp1[i], b = sp2[i];
-                    cnt += sampson_inlier(E, a.x, a.y, b.x, b.y, thr2);
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-                if ((tid & 63) == 0 && cnt) atomicAdd(&s_counts[k * RPE_MAX_MODELS + m], cnt);
-            }
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int best = s.best_count, niters = s.niters, bk = -1, bm = -1;
-        if (M == 5) {
-            // ptsetreg.cpp: count == modelPoints -> runKernel on all points, first model kept
-            if (s_nm[0] > 0) { best = 5; bk = 0; bm = 0; s.best_iter = 0; s.best_model = 0; }
-            niters = 1;
-            s.next_iter = 1;
-            s.iters_run = 1;
-        } else {
-            for (int k = 0; k < kmax; ++k) {
-                const int it = s.next_iter + k;
-                if (it >= niters) break;
-                s.iters_run = it + 1;
-                const int nm = s_nm[k];
-                for (int m = 0; m < nm; ++m) {
-                    int good = s_counts[k * RPE_MAX_MODELS + m];
-                    if (good > max(best, 4)) {
-                        best = good; bk = k; bm = m; s.best_iter = it; s.best_model = m;
-                        niters = update_niters(nit_denom, nit_round, nit_num, M, good, niters);
-                    }
+                const int good = counts[(slot0 + k) * RPE_MAX_MODELS + m];
+                if (good > max(best, 4)) {
+                    best = good; bk = k; bm = m; s.best_iter = it; s.best_model = m;
+                    niters = update_niters(nit_denom, nit_round, nit_num, M, good, niters);
                 }
             }
-            s.next_iter += chunk;
         }
-        if (bk >= 0) {
-            const double *Eg = models + (((long long)pair * RPE_RANSAC_MAXCHUNK + bk) * RPE_MAX_MODELS + bm) * 9;
-            for (int e = 0; e < 9; ++e) { s.E[e] = Eg[e]; E_out[pair * 9 + e] = Eg[e]; }
-        }
-        s.best_count = best; s.niters = niters;
-        s.found = best > 0;
-        s.done = s.next_iter >= niters;
-        found[pair] = s.found;
-        st[pair] = s;
+        s.next_iter += chunk;
     }
+    if (bk >= 0) {
+        const double *Eg = models + ((slot0 + bk) * RPE_MAX_MODELS + bm) * 9;
+        for (int e = 0; e < 9; ++e) { s.E[e] = Eg[e]; E_out[pair * 9 + e] = Eg[e]; }
+    }
+    s.best_count = best; s.niters = niters;
+    s.found = best > 0;
+    s.done = s.next_iter >= niters;
+    found[pair] = s.found;
+    st[pair] = s;
 }
 
 // ------------------------------------------------------------------- mask
@@ -624,9 +638,12 @@ void rpe_launch_ransac(rpe_handle *h, int B, bool want_mask)
                            n1, n2, h->d_rstate, h->d_subsets, h->d_hyp, h->d_nmodels, mm, it);
         hipLaunchKernelGGL(ransac_roots_kernel, dim3((B * wpp + 3) / 4), dim3(256), 0, h->stream,
                            (const RpeRansacState *)h->d_rstate, (const double *)h->d_hyp, h->d_models, h->d_nmodels, B, wpp);
-        hipLaunchKernelGGL(ransac_score_kernel, dim3(B), dim3(256), lds, h->stream,
-                           n1, n2, h->d_rstate, h->d_models, h->d_nmodels, h->d_K, h->d_nit_denom, h->d_nit_round,
-                           h->nit_num, h->cfg.ransac_threshold, h->d_E, h->d_found, mm, chunk);
+        hipLaunchKernelGGL(ransac_score_kernel, dim3(B, wpp), dim3(256), lds, h->stream,
+                           n1, n2, (const RpeRansacState *)h->d_rstate, (const double *)h->d_models, (const int *)h->d_nmodels,
+                           (const double *)h->d_K, h->cfg.ransac_threshold, h->d_counts, mm);
+        hipLaunchKernelGGL(ransac_update_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream,
+                           h->d_rstate, (const double *)h->d_models, (const int *)h->d_nmodels, (const int *)h->d_counts,
+                           (const double *)h->d_nit_denom, (const int *)h->d_nit_round, h->nit_num, h->d_E, h->d_found, chunk, B);
         done_iters += chunk;
         ++nlaunch;
         if (nlaunch >= 2 && chunk < RPE_RANSAC_MAXCHUNK) chunk *= 2;

@@ -260,6 +260,7 @@ static int alloc_workspace(rpe_handle *h)
     DM(h, h->d_models, B * RPE_RANSAC_MAXCHUNK * RPE_MAX_MODELS * 9);
     DM(h, h->d_hyp, B * (RPE_RANSAC_MAXCHUNK / 64) * 88 * 64);
     DM(h, h->d_nmodels, B * RPE_RANSAC_MAXCHUNK);
+    DM(h, h->d_counts, B * RPE_RANSAC_MAXCHUNK * RPE_MAX_MODELS);
     DM(h, h->d_mask, B * mm);
     DM(h, h->d_R, B * 9); DM(h, h->d_t, B * 3); DM(h, h->d_E, B * 9);
     DM(h, h->d_inliers, B); DM(h, h->d_status, B);
@@ -319,7 +320,7 @@ extern "C" void rpe_destroy(rpe_handle *h)
     void *ptrs[] = {h->d_tiles_full, h->d_tiles_fast, h->d_coef, h->d_pyr, h->d_bufA, h->d_bufB, h->d_stage1, h->d_stage2,
                     h->d_hist, h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_angle,
                     h->d_kp_pt, h->d_kp_cs, h->d_kp_count, h->d_desc, h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2,
-                    h->d_subsets, h->d_nit_denom, h->d_nit_round, h->d_rstate, h->d_n1, h->d_n2, h->d_found, h->d_models, h->d_hyp,
+                    h->d_subsets, h->d_nit_denom, h->d_nit_round, h->d_rstate, h->d_n1, h->d_n2, h->d_found, h->d_models, h->d_hyp, h->d_counts,
                     h->d_nmodels, h->d_mask, h->d_R, h->d_t, h->d_E, h->d_inliers, h->d_status, h->d_K};
     for (void *p : ptrs) if (p) hipFree(p);
     for (void *p : h->user_allocs) hipFree(p);

@@ -95,7 +95,8 @@ struct rpe_handle {
     int *d_found = nullptr;                   // [pair]
     double *d_hyp = nullptr;              // [pair][88][64] per-hypothesis record between the two solver kernels
     double *d_models = nullptr;           // [pair][CHUNK][10][9]
-    int *d_nmodels = nullptr;             // [pair][CHUNK]
+    int *d_nmodels = nullptr;             // [pair][MAXCHUNK]
+    int *d_counts = nullptr;              // [pair][MAXCHUNK][10] inlier counts of the current chunk
     uint8_t *d_mask = nullptr;            // [pair][max_matches]
     // results
     double *d_R = nullptr, *d_t = nullptr, *d_E = nullptr;
