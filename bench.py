@@ -117,17 +117,6 @@ def main():
 
     from relative_pose_estimation_amd import _capi, synthetic, geometry, sharding
 
-    dist = None
-    torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if args.dist_backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.dist_backend)
-
     method = "ORB"
     if args.config == 3:
         method = "SIFT"
@@ -157,6 +146,19 @@ def main():
         i1, i2, Rgt, tgt = synthetic.make_batch(B, K, W, H, cfg=2, first=rank * B, workers=workers)
         if cache:
             np.savez(cache, i1=i1, i2=i2, R=Rgt, t=tgt)
+
+    # the process group (and with it the HIP runtime) comes up only AFTER the synthetic batch exists:
+    # the generator forks worker processes, which must not inherit an initialised GPU context
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     ndev = _capi.load().rpe_device_count()
     device = local_rank % max(ndev, 1)

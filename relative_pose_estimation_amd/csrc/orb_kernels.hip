@@ -178,67 +178,75 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
     for (int i = tid; i < 64 * 16; i += 256) s_nms[i] = 0;
     __syncthreads();
     // ---- phase 1 (packed 16-bit SWAR: even / odd pixels of the dword group in one VGPR each)
+    // lane -> fixed dword column c (18 per row) and rows r0, r0+14, ... : the x-validity mask is
+    // computed once per tile and the candidate bits of the 5 rows are appended in one go
     const unsigned T1 = (unsigned)(thr + 1) * 0x00010001u, T0 = (unsigned)thr * 0x00010001u;
-    for (int g0 = 0; g0 < FS_ROWS * 18; g0 += 256) {
-        const int g = min(g0 + tid, FS_ROWS * 18 - 1);
-        const bool gvalid = g0 + tid < FS_ROWS * 18;      // loop is wave-uniform (shuffles below)
-        const int ry = g / 18, c = g - ry * 18;
-        const int ri = ry + 3;                       // input row of this score row
-        const int py = y0 - 1 + ry;
+    const int c = tid % 18, r0 = tid / 18;
+    unsigned cand_bits = 0;
+    if (tid < 252) {
         const int cl = max(c - 1, 0), cr = min(c + 1, 17);
-        const unsigned cdw = s_in[ri * 18 + c], ldw = s_in[ri * 18 + cl], rdw = s_in[ri * 18 + cr];
-        const unsigned upl = s_in[(ri - 2) * 18 + cl], upc = s_in[(ri - 2) * 18 + c], upr = s_in[(ri - 2) * 18 + cr];
-        const unsigned dnl = s_in[(ri + 2) * 18 + cl], dnc = s_in[(ri + 2) * 18 + c], dnr = s_in[(ri + 2) * 18 + cr];
-        unsigned mask2[2];
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            // v_perm_b32 picks bytes (sh+par, sh+par+2) of {hi:lo} into the low bytes of two 16-bit lanes
-#define PK2(hi, lo, sh) __builtin_bit_cast(short2_t, __builtin_amdgcn_perm((hi), (lo), 0x0c000c00u | (unsigned)((sh) + par) | ((unsigned)((sh) + par + 2) << 16)))
-            const short2_t ce = PK2(0u, cdw, 0);
-            short2_t d[8];
-            d[0] = ce - PK2(0u, s_in[(ri + 3) * 18 + c], 0);   // ( 0, 3)
-            d[1] = ce - PK2(0u, s_in[(ri - 3) * 18 + c], 0);   // ( 0,-3)
-            d[2] = ce - PK2(rdw, cdw, 3);                      // ( 3, 0)
-            d[3] = ce - PK2(cdw, ldw, 1);                      // (-3, 0)
-            d[4] = ce - PK2(dnr, dnc, 2);                      // ( 2, 2)
-            d[5] = ce - PK2(upc, upl, 2);                      // (-2,-2)
-            d[6] = ce - PK2(upr, upc, 2);                      // ( 2,-2)
-            d[7] = ce - PK2(dnc, dnl, 2);                      // (-2, 2)
-#undef PK2
-            // opposite pairs: (0,1) (2,3) (4,5) (6,7)
-            short2_t bmin = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(d[0], d[1]), __builtin_elementwise_max(d[2], d[3])),
-                                                      __builtin_elementwise_min(__builtin_elementwise_max(d[4], d[5]), __builtin_elementwise_max(d[6], d[7])));
-            short2_t dmax = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(d[0], d[1]), __builtin_elementwise_min(d[2], d[3])),
-                                                      __builtin_elementwise_max(__builtin_elementwise_min(d[4], d[5]), __builtin_elementwise_min(d[6], d[7])));
-            // bmin > thr  <=>  bmin - (thr+1) >= 0 ;  dmax < -thr  <=>  dmax + thr < 0
-            const unsigned u = __builtin_bit_cast(unsigned, bmin - __builtin_bit_cast(short2_t, T1));
-            const unsigned q = __builtin_bit_cast(unsigned, dmax + __builtin_bit_cast(short2_t, T0));
-            mask2[par] = (~u | q) & 0x80008000u;
-        }
-        unsigned candmask = ((mask2[0] >> 15) & 1u) | (((mask2[1] >> 15) & 1u) << 1) | (((mask2[0] >> 31) & 1u) << 2) | (((mask2[1] >> 31) & 1u) << 3);
-        // scores are consumed on [30, w-30) x [30, h-30) only (NMS of border-filtered pixels)
         const int pxb = x0 - 4 + 4 * c;
         const int xlo = max(x0 - 1, RPE_EDGE - 1), xhi = min(x0 + 64, w - RPE_EDGE);   // valid px range (inclusive)
         unsigned vmask = 0xFu;
         if (pxb < xlo) vmask &= 0xFu << min(xlo - pxb, 4);
         if (pxb + 3 > xhi) vmask &= 0xFu >> min(pxb + 3 - xhi, 4);
-        if (!(gvalid && py >= RPE_EDGE - 1 && py < hgt - RPE_EDGE + 1)) vmask = 0;
-        candmask &= vmask;
-        // wave-aggregated append: 4 ballots + mbcnt prefix counts (VALU/SALU only), one LDS
-        // atomic per wave; list order is irrelevant
-        const unsigned long long b0 = __ballot(candmask & 1u), b1 = __ballot(candmask & 2u),
-                                 b2 = __ballot(candmask & 4u), b3 = __ballot(candmask & 8u);
-        if (b0 | b1 | b2 | b3) {
-            const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
+        vmask &= 0xFu;
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int ry = r0 + 14 * it;
+            const int py = y0 - 1 + ry;
+            if (vmask == 0 || ry >= FS_ROWS || py < RPE_EDGE - 1 || py >= hgt - RPE_EDGE + 1) continue;
+            const int ri = ry + 3;                       // input row of this score row
+            const unsigned cdw = s_in[ri * 18 + c], ldw = s_in[ri * 18 + cl], rdw = s_in[ri * 18 + cr];
+            const unsigned upl = s_in[(ri - 2) * 18 + cl], upc = s_in[(ri - 2) * 18 + c], upr = s_in[(ri - 2) * 18 + cr];
+            const unsigned dnl = s_in[(ri + 2) * 18 + cl], dnc = s_in[(ri + 2) * 18 + c], dnr = s_in[(ri + 2) * 18 + cr];
+            const unsigned bot = s_in[(ri + 3) * 18 + c], top = s_in[(ri - 3) * 18 + c];
+            unsigned mask2[2];
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                // v_perm_b32 picks bytes (sh+par, sh+par+2) of {hi:lo} into the low bytes of two 16-bit lanes
+#define PK2(hi, lo, sh) __builtin_bit_cast(short2_t, __builtin_amdgcn_perm((hi), (lo), 0x0c000c00u | (unsigned)((sh) + par) | ((unsigned)((sh) + par + 2) << 16)))
+                const short2_t ce = PK2(0u, cdw, 0);
+                short2_t d[8];
+                d[0] = ce - PK2(0u, bot, 0);          // ( 0, 3)
+                d[1] = ce - PK2(0u, top, 0);          // ( 0,-3)
+                d[2] = ce - PK2(rdw, cdw, 3);         // ( 3, 0)
+                d[3] = ce - PK2(cdw, ldw, 1);         // (-3, 0)
+                d[4] = ce - PK2(dnr, dnc, 2);         // ( 2, 2)
+                d[5] = ce - PK2(upc, upl, 2);         // (-2,-2)
+                d[6] = ce - PK2(upr, upc, 2);         // ( 2,-2)
+                d[7] = ce - PK2(dnc, dnl, 2);         // (-2, 2)
+#undef PK2
+                // opposite pairs: (0,1) (2,3) (4,5) (6,7)
+                short2_t bmin = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(d[0], d[1]), __builtin_elementwise_max(d[2], d[3])),
+                                                          __builtin_elementwise_min(__builtin_elementwise_max(d[4], d[5]), __builtin_elementwise_max(d[6], d[7])));
+                short2_t dmax = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(d[0], d[1]), __builtin_elementwise_min(d[2], d[3])),
+                                                          __builtin_elementwise_max(__builtin_elementwise_min(d[4], d[5]), __builtin_elementwise_min(d[6], d[7])));
+                // bmin > thr  <=>  bmin - (thr+1) >= 0 ;  dmax < -thr  <=>  dmax + thr < 0
+                const unsigned u = __builtin_bit_cast(unsigned, bmin - __builtin_bit_cast(short2_t, T1));
+                const unsigned q = __builtin_bit_cast(unsigned, dmax + __builtin_bit_cast(short2_t, T0));
+                mask2[par] = (~u | q) & 0x80008000u;
+            }
+            const unsigned m4 = ((mask2[0] >> 15) & 1u) | (((mask2[1] >> 15) & 1u) << 1) | (((mask2[0] >> 31) & 1u) << 2) | (((mask2[1] >> 31) & 1u) << 3);
+            cand_bits |= (m4 & vmask) << (4 * it);
+        }
+    }
+    {   // one append per tile: wave prefix sum of the per-lane counts, one LDS atomic per wave
+        const int n = __popc(cand_bits);
+        int inc = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int m = __shfl_up(inc, o); if (lane >= o) inc += m; }
+        const int total = __shfl(inc, 63);
+        if (total) {
             int base = 0;
-            if (lane == 0) base = atomicAdd(&s_ncand, n0 + n1 + n2 + n3);
-            base = __shfl(base, 0);
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            const unsigned short code = (unsigned short)((ry << 7) | (4 * c));
-            if (candmask & 1u) s_cand[base + __popcll(b0 & lt)] = code;
-            if (candmask & 2u) s_cand[base + n0 + __popcll(b1 & lt)] = code + 1;
-            if (candmask & 4u) s_cand[base + n0 + n1 + __popcll(b2 & lt)] = code + 2;
-            if (candmask & 8u) s_cand[base + n0 + n1 + n2 + __popcll(b3 & lt)] = code + 3;
+            if (lane == 63) base = atomicAdd(&s_ncand, total);
+            int pos = __shfl(base, 63) + inc - n;
+            unsigned bits = cand_bits;
+            while (bits) {
+                const int bpos = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                s_cand[pos++] = (unsigned short)(((r0 + 14 * (bpos >> 2)) << 7) | (4 * c + (bpos & 3)));
+            }
         }
     }
     __syncthreads();
@@ -291,8 +299,8 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
         const int px = x0 + 4 * tx, py = y0 + ty;
         if (py < hgt && px < pitch) *(unsigned *)(nms + ibase + (long long)py * pitch + px) = s_nms[ty * 16 + tx];
     }
-    unsigned c = s_hist[tid];
-    if (c) atomicAdd(&hist[((long long)blockIdx.y * RPE_NLEVELS + t.level) * 256 + tid], c);
+    const unsigned hc = s_hist[tid];
+    if (hc) atomicAdd(&hist[((long long)blockIdx.y * RPE_NLEVELS + t.level) * 256 + tid], hc);
 }
 
 void rpe_launch_fast(rpe_handle *h, int n_img)
