@@ -207,24 +207,27 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
                 // v_perm_b32 picks bytes (sh+par, sh+par+2) of {hi:lo} into the low bytes of two 16-bit lanes
 #define PK2(hi, lo, sh) __builtin_bit_cast(short2_t, __builtin_amdgcn_perm((hi), (lo), 0x0c000c00u | (unsigned)((sh) + par) | ((unsigned)((sh) + par + 2) << 16)))
                 const short2_t ce = PK2(0u, cdw, 0);
-                short2_t d[8];
-                d[0] = ce - PK2(0u, bot, 0);          // ( 0, 3)
-                d[1] = ce - PK2(0u, top, 0);          // ( 0,-3)
-                d[2] = ce - PK2(rdw, cdw, 3);         // ( 3, 0)
-                d[3] = ce - PK2(cdw, ldw, 1);         // (-3, 0)
-                d[4] = ce - PK2(dnr, dnc, 2);         // ( 2, 2)
-                d[5] = ce - PK2(upc, upl, 2);         // (-2,-2)
-                d[6] = ce - PK2(upr, upc, 2);         // ( 2,-2)
-                d[7] = ce - PK2(dnc, dnl, 2);         // (-2, 2)
+                // ring values r (not differences): with d = ce - r,
+                //   min_pairs max(d_a,d_b) = ce - max_pairs min(r_a,r_b),  max_pairs min(d_a,d_b) = ce - min_pairs max(r_a,r_b)
+                short2_t r[8];
+                r[0] = PK2(0u, bot, 0);          // ( 0, 3)
+                r[1] = PK2(0u, top, 0);          // ( 0,-3)
+                r[2] = PK2(rdw, cdw, 3);         // ( 3, 0)
+                r[3] = PK2(cdw, ldw, 1);         // (-3, 0)
+                r[4] = PK2(dnr, dnc, 2);         // ( 2, 2)
+                r[5] = PK2(upc, upl, 2);         // (-2,-2)
+                r[6] = PK2(upr, upc, 2);         // ( 2,-2)
+                r[7] = PK2(dnc, dnl, 2);         // (-2, 2)
 #undef PK2
                 // opposite pairs: (0,1) (2,3) (4,5) (6,7)
-                short2_t bmin = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(d[0], d[1]), __builtin_elementwise_max(d[2], d[3])),
-                                                          __builtin_elementwise_min(__builtin_elementwise_max(d[4], d[5]), __builtin_elementwise_max(d[6], d[7])));
-                short2_t dmax = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(d[0], d[1]), __builtin_elementwise_min(d[2], d[3])),
-                                                          __builtin_elementwise_max(__builtin_elementwise_min(d[4], d[5]), __builtin_elementwise_min(d[6], d[7])));
-                // bmin > thr  <=>  bmin - (thr+1) >= 0 ;  dmax < -thr  <=>  dmax + thr < 0
-                const unsigned u = __builtin_bit_cast(unsigned, bmin - __builtin_bit_cast(short2_t, T1));
-                const unsigned q = __builtin_bit_cast(unsigned, dmax + __builtin_bit_cast(short2_t, T0));
+                const short2_t lo = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(r[0], r[1]), __builtin_elementwise_min(r[2], r[3])),
+                                                              __builtin_elementwise_max(__builtin_elementwise_min(r[4], r[5]), __builtin_elementwise_min(r[6], r[7])));
+                const short2_t hi = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(r[0], r[1]), __builtin_elementwise_max(r[2], r[3])),
+                                                              __builtin_elementwise_min(__builtin_elementwise_max(r[4], r[5]), __builtin_elementwise_max(r[6], r[7])));
+                // darker arc possible:   ce - lo > thr  <=>  (ce - lo) - (thr+1) >= 0
+                // brighter arc possible: hi - ce > thr  <=>  (ce - hi) + thr < 0
+                const unsigned u = __builtin_bit_cast(unsigned, (ce - lo) - __builtin_bit_cast(short2_t, T1));
+                const unsigned q = __builtin_bit_cast(unsigned, (ce - hi) + __builtin_bit_cast(short2_t, T0));
                 mask2[par] = (~u | q) & 0x80008000u;
             }
             const unsigned m4 = ((mask2[0] >> 15) & 1u) | (((mask2[1] >> 15) & 1u) << 1) | (((mask2[0] >> 31) & 1u) << 2) | (((mask2[1] >> 31) & 1u) << 3);
