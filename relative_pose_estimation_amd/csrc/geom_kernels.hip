@@ -456,25 +456,159 @@ __global__ __launch_bounds__(64) void ransac_poly_kernel(const double2 *__restri
     nmodels[slot] = ok ? -1 : 0;          // -1: record valid, roots pending
 }
 
-// B: roots + back-substitution; no LDS, moderate registers => many waves per CU hide the f64 latency
+// B: roots + back-substitution, RG = 16 lanes per minimal sample.  The real roots of the degree-k
+// derivative split the line into <= k+1 intervals with at most one root of the degree-(k+1)
+// derivative each, and those intervals are independent: lane j of a group brackets and refines
+// interval j, the roots are compacted in interval order (ballot + n-th set bit + shuffle), so every
+// lane performs exactly the arithmetic the sequential oracle performs for that interval and the
+// root list comes out in the same order.  16x more waves than lane-per-sample and a 10x shorter
+// dependent chain per wave: the stage is f64-throughput bound instead of single-wave-latency bound.
+#define RG 16
+__device__ __forceinline__ int nth_set_bit(unsigned m, int k)
+{
+    for (int t = 0; t < k; ++t) m &= m - 1;
+    return m ? __ffs((int)m) - 1 : 0;
+}
+
+// crit: in = root #j of the level below (j < nr_prev), out = root #j of this level (j < return value)
+template <int K>
+__device__ __forceinline__ int roots_level_grp(const double (&c)[11], double &crit, int nr_prev, int j, int gbase)
+{
+    double p[11], dp[11];
+#pragma unroll
+    for (int i = 0; i <= 10; ++i) p[i] = c[i];
+#pragma unroll
+    for (int kk = 10; kk > K; --kk)
+#pragma unroll
+        for (int i = 0; i < kk; ++i) p[i] = p[i + 1] * (double)(i + 1);
+#pragma unroll
+    for (int i = 0; i < K; ++i) dp[i] = p[i + 1] * (double)(i + 1);
+    double mx = 0.;
+#pragma unroll
+    for (int i = 0; i < K; ++i) { double a = fabs(p[i]); if (a > mx) mx = a; }
+    double R = 1. + mx / fabs(p[K]);
+    if (!(R < 1e12)) R = 1e12;
+    const double below = __shfl_up(crit, 1);
+    double a = (j == 0) ? -R : below;
+    double b = (j == nr_prev) ? R : crit;
+    if (a < -R) a = -R;
+    if (b > R) b = R;
+    bool has = false;
+    double root = 0.;
+    if (j <= nr_prev && a < b) {
+        const int sa = horner_s<K>(p, a) > 0., sb = horner_s<K>(p, b) > 0.;
+        if (sa != sb) { root = refine_root_s<K>(p, dp, a, b, sa); has = true; }
+    }
+    const unsigned m = (unsigned)(__ballot(has) >> gbase) & 0xFFFFu;
+    crit = __shfl(root, gbase + nth_set_bit(m, j));
+    return __popc(m);
+}
+
 __global__ __launch_bounds__(256) void ransac_roots_kernel(const RpeRansacState *__restrict__ st, const double *__restrict__ hyp,
                                                             double *__restrict__ models, int *__restrict__ nmodels, int n_pairs,
                                                             int waves_per_pair)
 {
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int pair = gw / waves_per_pair, wv = gw - pair * waves_per_pair;
+    const int tid = threadIdx.x, j = tid & (RG - 1), gbase = tid & 63 & ~(RG - 1);
+    const long long sidx = (long long)blockIdx.x * (256 / RG) + (tid / RG);     // sample = (pair, wv, lane)
+    const int per_pair = waves_per_pair * 64;
+    const int pair = (int)(sidx / per_pair), rem = (int)(sidx - (long long)pair * per_pair);
+    const int wv = rem >> 6, lane = rem & 63;
     if (pair >= n_pairs) return;
     const RpeRansacState s = st[pair];
-    if (s.done || s.next_iter + wv * 64 >= s.niters) return;
+    if (s.done || s.next_iter + wv * 64 >= s.niters) return;          // uniform per workgroup
     const long long slot = (long long)pair * RPE_RANSAC_MAXCHUNK + wv * 64 + lane;
-    int nm = 0;
-    if (nmodels[slot] == -1) {
-        double E[90];
-        nm = five_point_roots(hyp + ((long long)pair * (RPE_RANSAC_MAXCHUNK / 64) + wv) * HYP_DOUBLES * 64 + lane, E);
-        double *dst = models + slot * (RPE_MAX_MODELS * 9);
-        for (int e = 0; e < nm * 9; ++e) dst[e] = E[e];
+    if (nmodels[slot] != -1) return;                                   // uniform per group
+    const double *rec = hyp + ((long long)pair * (RPE_RANSAC_MAXCHUNK / 64) + wv) * HYP_DOUBLES * 64 + lane;
+    double c10[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) c10[i] = rec[i * 64];
+    const int n = (int)rec[86 * 64];
+    double z = 0.;
+    int nroots;
+    if (n == 10) {
+        {
+            double p[11];
+#pragma unroll
+            for (int i = 0; i <= 10; ++i) p[i] = c10[i];
+#pragma unroll
+            for (int kk = 10; kk > 1; --kk)
+#pragma unroll
+                for (int i = 0; i < kk; ++i) p[i] = p[i + 1] * (double)(i + 1);
+            z = -p[0] / p[1];
+        }
+        nroots = 1;
+        nroots = roots_level_grp<2>(c10, z, nroots, j, gbase);
+        nroots = roots_level_grp<3>(c10, z, nroots, j, gbase);
+        nroots = roots_level_grp<4>(c10, z, nroots, j, gbase);
+        nroots = roots_level_grp<5>(c10, z, nroots, j, gbase);
+        nroots = roots_level_grp<6>(c10, z, nroots, j, gbase);
+        nroots = roots_level_grp<7>(c10, z, nroots, j, gbase);
+        nroots = roots_level_grp<8>(c10, z, nroots, j, gbase);
+        nroots = roots_level_grp<9>(c10, z, nroots, j, gbase);
+        nroots = roots_level_grp<10>(c10, z, nroots, j, gbase);
+    } else {
+        // trimmed leading coefficient (rare): the group leader runs the generic chain serially
+        double rl[10];
+#pragma unroll
+        for (int t = 0; t < 10; ++t) rl[t] = 0.;
+        int nr = 0;
+        if (j == 0) nr = poly_real_roots_generic(c10, n, rl);
+        nroots = __shfl(nr, gbase);
+#pragma unroll
+        for (int t = 0; t < 10; ++t) { const double v = __shfl(rl[t], gbase); if (j == t) z = v; }
     }
-    nmodels[slot] = nm;
+    // back-substitution: lane j <- root #j (five_point_roots' loop body), models compacted in root order
+    bool okm = false;
+    double Ev[9];
+    if (j < nroots) {
+        double bz[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double x3 = rec[(11 + i * 4 + 3) * 64], x2 = rec[(11 + i * 4 + 2) * 64], x1 = rec[(11 + i * 4 + 1) * 64], x0 = rec[(11 + i * 4) * 64];
+            const double y3 = rec[(23 + i * 4 + 3) * 64], y2 = rec[(23 + i * 4 + 2) * 64], y1 = rec[(23 + i * 4 + 1) * 64], y0 = rec[(23 + i * 4) * 64];
+            const double w4 = rec[(35 + i * 5 + 4) * 64], w3 = rec[(35 + i * 5 + 3) * 64], w2 = rec[(35 + i * 5 + 2) * 64],
+                         w1 = rec[(35 + i * 5 + 1) * 64], w0 = rec[(35 + i * 5) * 64];
+            bz[i][0] = ((x3 * z + x2) * z + x1) * z + x0;
+            bz[i][1] = ((y3 * z + y2) * z + y1) * z + y0;
+            bz[i][2] = (((w4 * z + w3) * z + w2) * z + w1) * z + w0;
+        }
+        double bestn = -1., xv0 = 0., xv1 = 0., xv2 = 0.;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int r0 = i, r1 = (i + 1) % 3;
+            const double cx = bz[r0][1] * bz[r1][2] - bz[r0][2] * bz[r1][1];
+            const double cy = bz[r0][2] * bz[r1][0] - bz[r0][0] * bz[r1][2];
+            const double cz = bz[r0][0] * bz[r1][1] - bz[r0][1] * bz[r1][0];
+            const double nn = cx * cx + cy * cy + cz * cz;
+            if (nn > bestn) { bestn = nn; xv0 = cx; xv1 = cy; xv2 = cz; }
+        }
+        if (bestn > 0.) {
+            const double inv = 1. / sqrt(bestn);
+            const double w = xv2 * inv;
+            if (!(fabs(w) < 1e-10)) {
+                const double x = xv0 / xv2, y = xv1 / xv2;
+                double nrm = 0.;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) {
+                    Ev[e] = ((rec[(50 + e) * 64] * x + rec[(59 + e) * 64] * y) + rec[(68 + e) * 64] * z) + rec[(77 + e) * 64];
+                    nrm += Ev[e] * Ev[e];
+                }
+                nrm = sqrt(nrm);
+                if (nrm > 0.) {
+                    okm = true;
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) Ev[e] = Ev[e] / nrm;
+                }
+            }
+        }
+    }
+    const unsigned m = (unsigned)(__ballot(okm) >> gbase) & 0xFFFFu;
+    if (okm) {
+        double *dst = models + (slot * RPE_MAX_MODELS + __popc(m & ((1u << j) - 1u))) * 9;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) dst[e] = Ev[e];
+    }
+    if (j == 0) nmodels[slot] = __popc(m);
 }
 
 // ------------------------------------------------------- Sampson inlier test
@@ -636,7 +770,7 @@ void rpe_launch_ransac(rpe_handle *h, int B, bool want_mask)
         const int wpp = chunk / 64;
         hipLaunchKernelGGL(ransac_poly_kernel, dim3(B, wpp), dim3(64), 0, h->stream,
                            n1, n2, h->d_rstate, h->d_subsets, h->d_hyp, h->d_nmodels, mm, it);
-        hipLaunchKernelGGL(ransac_roots_kernel, dim3((B * wpp + 3) / 4), dim3(256), 0, h->stream,
+        hipLaunchKernelGGL(ransac_roots_kernel, dim3(B * wpp * (64 * RG / 256)), dim3(256), 0, h->stream,
                            (const RpeRansacState *)h->d_rstate, (const double *)h->d_hyp, h->d_models, h->d_nmodels, B, wpp);
         hipLaunchKernelGGL(ransac_score_kernel, dim3(B, wpp), dim3(256), lds, h->stream,
                            n1, n2, (const RpeRansacState *)h->d_rstate, (const double *)h->d_models, (const int *)h->d_nmodels,
