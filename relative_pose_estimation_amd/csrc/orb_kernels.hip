@@ -614,13 +614,13 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
             const unsigned w0 = rw[d0], w1 = rw[d0 + 1], w2 = rw[min(d0 + 2, KP_RAW_DW - 1)], w3 = rw[min(d0 + 3, KP_RAW_DW - 1)];
             const unsigned q0 = __builtin_amdgcn_alignbyte(w1, w0, sh), q1 = __builtin_amdgcn_alignbyte(w2, w1, sh),
                            q2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
-            unsigned px[12];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { px[t] = (q0 >> (8 * t)) & 255; px[4 + t] = (q1 >> (8 * t)) & 255; px[8 + t] = (q2 >> (8 * t)) & 255; }
+            // taps [18,34,48,56 | 48,34,18,0] as two packed-u8 dot products per output (v_dot4_u32_u8)
+            const unsigned W0 = 18u | (34u << 8) | (48u << 16) | (56u << 24), W1 = 48u | (34u << 8) | (18u << 16);
             unsigned o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                o[j] = 18u * px[j] + 34u * px[j + 1] + 48u * px[j + 2] + 56u * px[j + 3] + 48u * px[j + 4] + 34u * px[j + 5] + 18u * px[j + 6];
+            o[0] = __builtin_amdgcn_udot4(q1, W1, __builtin_amdgcn_udot4(q0, W0, 0u, false), false);
+            o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(q2, q1, 1), W1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(q1, q0, 1), W0, 0u, false), false);
+            o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(q2, q1, 2), W1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(q1, q0, 2), W0, 0u, false), false);
+            o[3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(q2, q1, 3), W1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(q1, q0, 3), W0, 0u, false), false);
             hb[r * KP_H_DW + 2 * gq] = o[0] | (o[1] << 16);
             hb[r * KP_H_DW + 2 * gq + 1] = o[2] | (o[3] << 16);
         }
