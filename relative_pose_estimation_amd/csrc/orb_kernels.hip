@@ -309,8 +309,11 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
 void rpe_launch_fast(rpe_handle *h, int n_img)
 {
     hipMemsetAsync(h->d_hist, 0, sizeof(unsigned) * 256 * RPE_NLEVELS * (size_t)n_img, h->stream);
-    hipLaunchKernelGGL(fast_nms_kernel, dim3((h->n_tiles_full + 7) / 8 * 8, n_img), dim3(256), 0, h->stream,
-                       h->d_pyr, h->d_bufB, h->d_hist, h->lay, h->d_tiles_full, h->n_tiles_full);
+    // tiles cover the border-filtered region only; the rest of the NMS map was zeroed at handle
+    // creation and is never written
+    if (h->n_tiles_fast == 0) return;
+    hipLaunchKernelGGL(fast_nms_kernel, dim3((h->n_tiles_fast + 7) / 8 * 8, n_img), dim3(256), 0, h->stream,
+                       h->d_pyr, h->d_bufB, h->d_hist, h->lay, h->d_tiles_fast, h->n_tiles_fast);
 }
 
 void rpe_launch_nms(rpe_handle *h, int n_img) { (void)h; (void)n_img; }   // fused into fast_nms_kernel

@@ -133,8 +133,9 @@ static int build_tables(rpe_handle *h)
         for (int y = 0; y < v.h; y += 64)
             for (int x = 0; x < v.pitch; x += 64) full.push_back({(short)l, (short)x, (short)y, 0});
         if (v.w > 2 * RPE_EDGE && v.h > 2 * RPE_EDGE)
-            for (int y = 28; y < v.h - 28; y += 64)
-                for (int x = 28; x < v.w - 28; x += 64) fast.push_back({(short)l, (short)x, (short)y, 0});
+            // keypoints survive the border filter on [31, w-31) x [31, h-31) only; x origin dword aligned
+            for (int y = RPE_EDGE; y < v.h - RPE_EDGE; y += 64)
+                for (int x = RPE_EDGE & ~3; x < v.w - RPE_EDGE; x += 64) fast.push_back({(short)l, (short)x, (short)y, 0});
     }
     h->n_tiles_full = (int)full.size(); h->n_tiles_fast = (int)fast.size();
     DM(h, h->d_tiles_full, full.size());
