@@ -371,8 +371,10 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const uint8_t *_
     }
     __syncthreads();
     const int tau = s_tau;
-    const uint8_t *src = nms + (long long)img * lay.stride + L.off;
-    const int nbytes = L.pitch * L.h;
+    // rows [31, h-31) only: the border band of the NMS map is zero by construction
+    const int row0 = (L.h > 2 * RPE_EDGE) ? RPE_EDGE : 0;
+    const uint8_t *src = nms + (long long)img * lay.stride + L.off + row0 * L.pitch;
+    const int nbytes = L.pitch * (L.h - 2 * row0);
     const int ccap = L.ccap;
     unsigned *out = cand_xy + (long long)img * lay.cand_total + L.cand_off;
     int base = 0;
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const uint8_t *_
             for (int k = 0; k < 16; ++k) {
                 int b = (int)((wds[k >> 2] >> (8 * (k & 3))) & 255);
                 if (b >= tau) {
-                    if (o < ccap) { int p = pos + k; int y = p / L.pitch; int x = p - y * L.pitch; out[o] = ((unsigned)y << 16) | (unsigned)x; }
+                    if (o < ccap) { int p = pos + k; int y = p / L.pitch; int x = p - y * L.pitch; out[o] = ((unsigned)(y + row0) << 16) | (unsigned)x; }
                     ++o;
                 }
             }
@@ -471,81 +473,97 @@ __device__ __forceinline__ unsigned float_key(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__global__ __launch_bounds__(256) void select_keypoints_kernel(const unsigned *__restrict__ cand_xy, const float *__restrict__ cand_resp,
-                                                                const int *__restrict__ cand_count,
-                                                                unsigned *__restrict__ kp_xy, float *__restrict__ kp_resp,
-                                                                float2 *__restrict__ kp_pt, int *__restrict__ kp_count,
-                                                                RpeDeviceLayout lay)
+// One workgroup per image, one WAVE per pyramid level: the 12 radix selects run side by side
+// (the first version walked the levels one after the other with a serial 256-bin scan per pass and
+// was pure latency).  Per level: 4 radix passes over the order-preserving keys (LDS histogram per
+// wave, descending bin scan with 4 bins per lane + wave prefix sum), count of survivors, then --
+// once every level's count is known -- raster-ordered compaction by ballot at the level's offset.
+// All waves execute the same number of barriers (levels with n <= quota run the passes too and
+// ignore the result).
+__global__ __launch_bounds__(64 * RPE_NLEVELS) void select_keypoints_kernel(const unsigned *__restrict__ cand_xy, const float *__restrict__ cand_resp,
+                                                                             const int *__restrict__ cand_count,
+                                                                             unsigned *__restrict__ kp_xy, float *__restrict__ kp_resp,
+                                                                             float2 *__restrict__ kp_pt, int *__restrict__ kp_count,
+                                                                             RpeDeviceLayout lay)
 {
-    __shared__ unsigned s_hist[256];
-    __shared__ int s_wave[5];
-    __shared__ unsigned s_prefix;
-    __shared__ int s_kk;
-    const int tid = threadIdx.x, img = blockIdx.x;
+    __shared__ unsigned s_hist[RPE_NLEVELS][256];
+    __shared__ int s_cnt[RPE_NLEVELS];
+    const int lane = threadIdx.x & 63, l = threadIdx.x >> 6, img = blockIdx.x;
     const int kcap = lay.kcap;
-    int offset = 0;
-    for (int l = 0; l < RPE_NLEVELS; ++l) {
-        const RpeLevel &L = lay.lv[l];
-        const int n = cand_count[img * RPE_NLEVELS + l];
-        const int q = L.quota;
-        const float *resp = cand_resp + (long long)img * lay.cand_total + L.cand_off;
-        const unsigned *xy = cand_xy + (long long)img * lay.cand_total + L.cand_off;
-        unsigned thr_key = 0;
-        if (n > q) {
-            unsigned prefix = 0, mask = 0;
-            if (tid == 0) s_kk = q;
-            for (int pass = 3; pass >= 0; --pass) {
-                const int shift = 8 * pass;
-                s_hist[tid] = 0;
-                __syncthreads();
-                for (int i = tid; i < n; i += 256) {
-                    unsigned key = float_key(resp[i]);
-                    if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255], 1u);
-                }
-                __syncthreads();
-                if (tid == 0) {
-                    int kk = s_kk, acc = 0, bin = 0;
-                    for (int b = 255; b >= 0; --b) {
-                        int c = (int)s_hist[b];
-                        if (acc + c >= kk) { bin = b; break; }
-                        acc += c;
-                    }
-                    s_kk = kk - acc;
-                    s_prefix = prefix | ((unsigned)bin << shift);
-                }
-                __syncthreads();
-                prefix = s_prefix;
-                mask |= 255u << shift;
-            }
-            thr_key = prefix;
-        }
-        for (int c0 = 0; c0 < n; c0 += 256) {
-            int i = c0 + tid;
-            float r = 0.f; bool keep = false;
-            if (i < n) { r = resp[i]; keep = float_key(r) >= thr_key; }
-            int total;
-            int ex = block_excl_scan(keep ? 1 : 0, s_wave, total);
-            if (keep) {
-                int o = offset + ex;
-                if (o < kcap) {
-                    unsigned p = xy[i];
-                    int x = p & 0xFFFF, y = p >> 16;
-                    long long g = (long long)img * kcap + o;
-                    kp_xy[g] = (unsigned)x | ((unsigned)y << 12) | ((unsigned)l << 24);
-                    kp_resp[g] = r;
-                    kp_pt[g] = make_float2((float)x * L.scale, (float)y * L.scale);
-                }
-            }
-            offset += total;
+    const RpeLevel &L = lay.lv[l];
+    const int n = cand_count[img * RPE_NLEVELS + l];
+    const int q = L.quota;
+    const float *resp = cand_resp + (long long)img * lay.cand_total + L.cand_off;
+    const unsigned *xy = cand_xy + (long long)img * lay.cand_total + L.cand_off;
+    unsigned *hist = s_hist[l];
+    unsigned prefix = 0, mask = 0;
+    int kk = q;
+    for (int pass = 3; pass >= 0; --pass) {
+        const int shift = 8 * pass;
+        hist[lane] = 0; hist[lane + 64] = 0; hist[lane + 128] = 0; hist[lane + 192] = 0;
+        __syncthreads();
+        for (int i = lane; i < n; i += 64) {
+            const unsigned key = float_key(resp[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
         }
         __syncthreads();
+        // first bin (descending) where the running count reaches kk
+        const int b0 = 255 - 4 * lane;
+        const int c0 = (int)hist[b0], c1 = (int)hist[b0 - 1], c2 = (int)hist[b0 - 2], c3 = (int)hist[b0 - 3];
+        const int sum = c0 + c1 + c2 + c3;
+        int inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int m = __shfl_up(inc, o); if (lane >= o) inc += m; }
+        const int before = inc - sum;
+        int fb = -1, fa = 0;
+        if (before < kk && inc >= kk) {
+            int a = before;
+            if (a + c0 >= kk) { fb = b0; fa = a; }
+            else { a += c0; if (a + c1 >= kk) { fb = b0 - 1; fa = a; }
+                   else { a += c1; if (a + c2 >= kk) { fb = b0 - 2; fa = a; } else { a += c2; fb = b0 - 3; fa = a; } } }
+        }
+        const unsigned long long bm = __ballot(fb >= 0);
+        const int srcl = bm ? (__ffsll((long long)bm) - 1) : 0;
+        const int bin = max(__shfl(fb, srcl), 0), acc = __shfl(fa, srcl);
+        kk -= acc;
+        prefix |= (unsigned)bin << shift;
+        mask |= 255u << shift;
+        __syncthreads();
     }
-    if (tid == 0) kp_count[img] = min(offset, kcap);
+    const unsigned thr_key = (n > q) ? prefix : 0u;
+    int cnt = 0;
+    for (int i = lane; i < n; i += 64) cnt += float_key(resp[i]) >= thr_key;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) s_cnt[l] = cnt;
+    __syncthreads();
+    int offset = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < RPE_NLEVELS; ++k) { const int c = s_cnt[k]; if (k < l) offset += c; total += c; }
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int i = c0 + lane;
+        float r = 0.f; bool keep = false;
+        if (i < n) { r = resp[i]; keep = float_key(r) >= thr_key; }
+        const unsigned long long km = __ballot(keep);
+        if (keep) {
+            const int o = offset + __popcll(km & ((1ull << lane) - 1ull));
+            if (o < kcap) {
+                const unsigned p = xy[i];
+                const int x = p & 0xFFFF, y = p >> 16;
+                const long long g = (long long)img * kcap + o;
+                kp_xy[g] = (unsigned)x | ((unsigned)y << 12) | ((unsigned)l << 24);
+                kp_resp[g] = r;
+                kp_pt[g] = make_float2((float)x * L.scale, (float)y * L.scale);
+            }
+        }
+        offset += __popcll(km);
+    }
+    if (threadIdx.x == 0) kp_count[img] = min(total, kcap);
 }
 
 void rpe_launch_keypoints(rpe_handle *h, int n_img)
 {
-    hipLaunchKernelGGL(select_keypoints_kernel, dim3(n_img), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL(select_keypoints_kernel, dim3(n_img), dim3(64 * RPE_NLEVELS), 0, h->stream,
                        h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_pt,
                        h->d_kp_count, h->lay);
 }
