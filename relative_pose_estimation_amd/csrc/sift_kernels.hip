@@ -53,6 +53,7 @@ struct RpeSiftState {
     int *d_nraw = nullptr, *d_overflow = nullptr, *d_ncand = nullptr;
     unsigned long long *d_k0 = nullptr, *d_k1 = nullptr; unsigned *d_sidx = nullptr; // sort keys [img][raw_pad]
     int raw_pad = 0;
+    int ks[6] = {0, 0, 0, 0, 0, 0};                      // tap counts of c_skern
     float *d_fin = nullptr;                                // [img][kcap][6] un-halved keypoints in sorted order
 };
 
@@ -113,6 +114,74 @@ __global__ __launch_bounds__(256) void sift_blur_col_kernel(const float *__restr
     dst[(long long)blockIdx.z * dstride + (size_t)y * w + x] = acc;
 }
 
+// Fused separable Gaussian + DoG: one workgroup = 64x64 output pixels of one pyramid level.
+// The (64+2R)^2 source window (reflect-101 resolved at load time) is staged in LDS once, the row
+// pass runs on all 64+2R window rows into a second LDS plane, the column pass reads that plane and
+// writes G[i]; DoG[i-1] = G[i] - G[i-1] comes from the window centre, so the level is read once and
+// the two results are written once (the unfused version went through HBM between the passes and
+// read every level again for the DoG).  Each lane accumulates 8 neighbouring outputs from a
+// register window of 8+2R values; tap order and accumulation order are the oracle's
+// (acc = 0; acc += k[i]*v[i], i ascending), so the f32 results are bit-identical.
+template <int R>
+__global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__restrict__ src, long long sstride, float *__restrict__ dst,
+                                                               long long dstride, float *__restrict__ dog, long long dogstride,
+                                                               int w, int h, int kid, int tcols, int ntiles)
+{
+    constexpr int WIN = 64 + 2 * R, SP = WIN + 1, KS = 2 * R + 1;
+    __shared__ float s_src[WIN * SP];
+    __shared__ float s_tmp[WIN * 64];
+    const int tid = threadIdx.x;
+    const int ti = blockIdx.x;
+    if (ti >= ntiles) return;
+    const int x0 = (ti % tcols) * 64, y0 = (ti / tcols) * 64;
+    const float *s = src + (long long)blockIdx.y * sstride;
+    for (int i = tid; i < WIN * WIN; i += 256) {
+        const int r = i / WIN, c = i - r * WIN;
+        s_src[r * SP + c] = s[(size_t)s_refl(y0 + r - R, h) * w + s_refl(x0 + c - R, w)];
+    }
+    float k[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) k[i] = c_skern[kid][i];
+    __syncthreads();
+    // row pass: item = (window row, group of 8 columns)
+    for (int it = tid; it < WIN * 8; it += 256) {
+        const int r = it >> 3, g = it & 7;
+        const float *row = s_src + r * SP + 8 * g;
+        float v[8 + 2 * R];
+#pragma unroll
+        for (int i = 0; i < 8 + 2 * R; ++i) v[i] = row[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < KS; ++i) acc += k[i] * v[j + i];
+            s_tmp[r * 64 + 8 * g + j] = acc;
+        }
+    }
+    __syncthreads();
+    // column pass: item = (column, group of 8 rows)
+    const long long ob = (long long)blockIdx.y * dstride, db = (long long)blockIdx.y * dogstride;
+    for (int it = tid; it < 64 * 8; it += 256) {
+        const int c = it & 63, g = it >> 6;
+        const float *col = s_tmp + (8 * g) * 64 + c;
+        float v[8 + 2 * R];
+#pragma unroll
+        for (int i = 0; i < 8 + 2 * R; ++i) v[i] = col[i * 64];
+        const int x = x0 + c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < KS; ++i) acc += k[i] * v[j + i];
+            const int y = y0 + 8 * g + j;
+            if (x < w && y < h) {
+                dst[ob + (size_t)y * w + x] = acc;
+                if (dog) dog[db + (size_t)y * w + x] = acc - s_src[(8 * g + j + R) * SP + c + R];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void sift_halve_kernel(const float *__restrict__ src, float *__restrict__ dst, long long stride,
                                                           int sw, int w, int h)
 {
@@ -122,16 +191,13 @@ __global__ __launch_bounds__(256) void sift_halve_kernel(const float *__restrict
     dst[b + (size_t)y * w + x] = src[b + (size_t)(2 * y) * sw + 2 * x];
 }
 
-__global__ __launch_bounds__(256) void sift_dog_kernel(const float *__restrict__ g, long long gstride, float *__restrict__ d,
-                                                        long long dstride, long long n /* w*h */)
+// d = a - b (DoG of one level pair; only the unfused fallback path uses it)
+__global__ __launch_bounds__(256) void sift_sub_kernel(const float *__restrict__ a, long long astride, const float *__restrict__ b,
+                                                        long long bstride, float *__restrict__ d, long long dstride, long long n)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float *gg = g + (long long)blockIdx.z * gstride;
-    float *dd = d + (long long)blockIdx.z * dstride;
-    float prev = gg[i];
-#pragma unroll
-    for (int l = 0; l < S_ND; ++l) { float nx = gg[(l + 1) * n + i]; dd[l * n + i] = nx - prev; prev = nx; }
+    d[(long long)blockIdx.z * dstride + i] = a[(long long)blockIdx.z * astride + i] - b[(long long)blockIdx.z * bstride + i];
 }
 
 // ------------------------------------------------------------------ extrema
@@ -693,6 +759,7 @@ int rpe_sift_create(rpe_handle *h)
     }
     SCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_skern), kern, sizeof(kern)));
     SCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_sks), ks, sizeof(ks)));
+    for (int i = 0; i < 6; ++i) S->ks[i] = ks[i];
     // row bands for the extrema passes, in the oracle's enumeration order (octave, layer, row)
     std::vector<SiftBand> bands;
     for (int o = 0; o < dv.noct; ++o) {
@@ -738,12 +805,32 @@ void rpe_sift_destroy(rpe_handle *h)
     h->sift = nullptr;
 }
 
-static void sift_blur(rpe_handle *h, const float *src, long long sstride, float *dst, long long dstride, int w, int hh, int kid, int n_img)
+template <int R>
+static void sift_blur_launch(rpe_handle *h, const float *src, long long sstride, float *dst, long long dstride, float *dog,
+                             long long dogstride, int w, int hh, int kid, int n_img)
 {
-    RpeSiftState *S = h->sift;
-    float *tmp = S->d_tmp + (long long)h->n_img_cap * S->dv.tstride;      // second half of d_tmp: row-pass output
-    hipLaunchKernelGGL(sift_blur_row_kernel, dim3((w + 255) / 256, hh, n_img), dim3(256), 0, h->stream, src, sstride, tmp, S->dv.tstride, w, hh, kid);
-    hipLaunchKernelGGL(sift_blur_col_kernel, dim3((w + 255) / 256, hh, n_img), dim3(256), 0, h->stream, (const float *)tmp, S->dv.tstride, dst, dstride, w, hh, kid);
+    const int tcols = (w + 63) / 64, ntiles = tcols * ((hh + 63) / 64);
+    hipLaunchKernelGGL(sift_blur_fused_kernel<R>, dim3(ntiles, n_img), dim3(256), 0, h->stream, src, sstride, dst, dstride, dog, dogstride,
+                       w, hh, kid, tcols, ntiles);
+}
+
+// G[dst] = gauss(kid) * G[src]; dog (optional) = G[dst] - G[src]
+static void sift_blur(rpe_handle *h, const float *src, long long sstride, float *dst, long long dstride, float *dog, long long dogstride,
+                      int w, int hh, int kid, int n_img)
+{
+    switch (h->sift->ks[kid] >> 1) {
+    case 5:  sift_blur_launch<5>(h, src, sstride, dst, dstride, dog, dogstride, w, hh, kid, n_img); break;
+    case 6:  sift_blur_launch<6>(h, src, sstride, dst, dstride, dog, dogstride, w, hh, kid, n_img); break;
+    case 8:  sift_blur_launch<8>(h, src, sstride, dst, dstride, dog, dogstride, w, hh, kid, n_img); break;
+    case 10: sift_blur_launch<10>(h, src, sstride, dst, dstride, dog, dogstride, w, hh, kid, n_img); break;
+    case 13: sift_blur_launch<13>(h, src, sstride, dst, dstride, dog, dogstride, w, hh, kid, n_img); break;
+    default: {      // any other width: unfused two-pass path
+        float *tmp = h->sift->d_tmp + (long long)h->n_img_cap * h->sift->dv.tstride;
+        hipLaunchKernelGGL(sift_blur_row_kernel, dim3((w + 255) / 256, hh, n_img), dim3(256), 0, h->stream, src, sstride, tmp, h->sift->dv.tstride, w, hh, kid);
+        hipLaunchKernelGGL(sift_blur_col_kernel, dim3((w + 255) / 256, hh, n_img), dim3(256), 0, h->stream, (const float *)tmp, h->sift->dv.tstride, dst, dstride, w, hh, kid);
+        if (dog) hipLaunchKernelGGL(sift_sub_kernel, dim3((unsigned)(((long long)w * hh + 255) / 256), 1, n_img), dim3(256), 0, h->stream,
+                                    (const float *)dst, dstride, src, sstride, dog, dogstride, (long long)w * hh);
+    } }
 }
 
 // d_imgs: n_img tightly packed u8 images already resident (d_a followed by d_b as in the ORB path)
@@ -761,7 +848,7 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
                            S->d_tmp + (long long)first * dv.tstride, dv.tstride);
     }
     const int n = na + nb;
-    sift_blur(h, S->d_tmp, dv.tstride, S->d_gauss + dv.goff[0], dv.gstride, bw, bh, 0, n);
+    sift_blur(h, S->d_tmp, dv.tstride, S->d_gauss + dv.goff[0], dv.gstride, nullptr, 0, bw, bh, 0, n);
     // 2. gaussian pyramid + DoG
     for (int o = 0; o < dv.noct; ++o) {
         const int w = dv.w[o], hh = dv.h[o];
@@ -771,9 +858,8 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
                                (const float *)(S->d_gauss + dv.goff[o - 1] + (long long)S_NOL * dv.w[o - 1] * dv.h[o - 1]),
                                S->d_gauss + dv.goff[o], dv.gstride, dv.w[o - 1], w, hh);
         for (int i = 1; i < S_NG; ++i)
-            sift_blur(h, S->d_gauss + dv.goff[o] + (i - 1) * pn, dv.gstride, S->d_gauss + dv.goff[o] + i * pn, dv.gstride, w, hh, i, n);
-        hipLaunchKernelGGL(sift_dog_kernel, dim3((unsigned)((pn + 255) / 256), 1, n), dim3(256), 0, h->stream,
-                           (const float *)(S->d_gauss + dv.goff[o]), dv.gstride, S->d_dog + dv.doff[o], dv.dstride, pn);
+            sift_blur(h, S->d_gauss + dv.goff[o] + (i - 1) * pn, dv.gstride, S->d_gauss + dv.goff[o] + i * pn, dv.gstride,
+                      S->d_dog + dv.doff[o] + (i - 1) * pn, dv.dstride, w, hh, i, n);
     }
     // 3. seeds (count, scan, emit)
     hipLaunchKernelGGL(sift_extrema_kernel<false>, dim3(dv.nbands, n), dim3(256), 0, h->stream, (const float *)S->d_dog, dv,
