@@ -33,7 +33,7 @@
 __constant__ float c_skern[6][32];     // [0] initial blur, [1..5] incremental octave blurs
 __constant__ int c_sks[6];
 
-struct SiftBand { short o, l; int r0, r1; };
+struct SiftXTile { int o, x0, y0; };     // 64x32 tile of the extrema scan
 
 struct SiftDev {                        // passed by value to kernels
     int noct;
@@ -41,12 +41,17 @@ struct SiftDev {                        // passed by value to kernels
     long long goff[12], doff[12];       // float offsets inside the per-image gaussian / DoG buffers
     long long gstride, dstride, tstride; // floats per image
     int seed_cap, raw_cap, kcap, nfeatures, nbands;
+    // extrema scan: a band = one row of one (octave, layer 1..3): index band0[o] + (l-1)*(h-10) + (r-5), i.e. the
+    // oracle's enumeration order (octave, layer, row); hits live in a 1-bit-per-pixel mask [3][h][wpr] of 64-bit words
+    int band0[12], wpr[12];
+    long long bmoff[12], bmstride;
 };
 
 struct RpeSiftState {
     SiftDev dv;
     float *d_gauss = nullptr, *d_dog = nullptr, *d_tmp = nullptr;
-    SiftBand *d_bands = nullptr;
+    SiftXTile *d_xtiles = nullptr; int n_xtiles = 0;
+    unsigned long long *d_xmask = nullptr;                 // [img][bmstride]
     int *d_band_cnt = nullptr, *d_band_off = nullptr;     // [img][nbands]
     unsigned *d_seeds = nullptr; int *d_nseeds = nullptr; // [img][seed_cap], [img]
     float *d_raw = nullptr;                                // [img][raw_cap][6]: x y size angle response octave(bits)
@@ -217,56 +222,118 @@ __device__ __forceinline__ int s_block_excl_scan(int v, int *s_wave, int &total)
     return base + inc - v;
 }
 
-__device__ __forceinline__ bool sift_is_extremum(const float *d, long long n, int w, int l, int r, int c)
+// Pass 1 (tiled, any order): 26-neighbour test of the three inner DoG layers of a 64x32 tile.  The
+// five layers roll through three LDS planes (each DoG value leaves HBM once per tile instead of up to
+// 27 times through the caches), one wave owns a row: the hit flags of a row are a 64-bit ballot =
+// one mask word, its popcount goes to the row's band counter (integer atomic: deterministic).
+#define SX_TW 64
+#define SX_TH 32
+#define SX_P 67
+__global__ __launch_bounds__(256) void sift_extrema_mask_kernel(const float *__restrict__ dog, SiftDev dv, const SiftXTile *__restrict__ tiles,
+                                                                 unsigned long long *__restrict__ mask, int *__restrict__ band_cnt)
 {
-    const float val = d[l * n + (size_t)r * w + c];
-    if (!(fabsf(val) > 1.f)) return false;
-    bool ismax = val > 0, ismin = val < 0;
-    for (int dl = -1; dl <= 1; ++dl)
-        for (int dr = -1; dr <= 1; ++dr) {
-            const float *p = d + (l + dl) * n + (size_t)(r + dr) * w + c;
-            float a = p[-1], b = p[0], e = p[1];
-            ismax = ismax && !(a > val) && !(b > val) && !(e > val);
-            ismin = ismin && !(a < val) && !(b < val) && !(e < val);
+    __shared__ float s_d[3][(SX_TH + 2) * SX_P];
+    const SiftXTile t = tiles[blockIdx.x];
+    const int img = blockIdx.y, o = t.o, w = dv.w[o], h = dv.h[o], x0 = t.x0, y0 = t.y0;
+    const long long n = (long long)w * h;
+    const float *d = dog + (long long)img * dv.dstride + dv.doff[o];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    auto load = [&](int layer, int slot) {
+        const float *src = d + layer * n;
+        for (int i = tid; i < (SX_TH + 2) * (SX_TW + 2); i += 256) {
+            const int r = i / (SX_TW + 2), c = i - r * (SX_TW + 2);
+            const int y = min(max(y0 - 1 + r, 0), h - 1), x = min(max(x0 - 1 + c, 0), w - 1);
+            s_d[slot][r * SX_P + c] = src[(size_t)y * w + x];
         }
-    return ismax || ismin;
+    };
+    load(0, 0); load(1, 1);
+    unsigned long long *mk = mask + (long long)img * dv.bmstride + dv.bmoff[o];
+    int *bc = band_cnt + (long long)img * dv.nbands + dv.band0[o];
+    for (int l = 1; l <= S_NOL; ++l) {
+        load(l + 1, (l + 1) % 3);
+        __syncthreads();
+        const float *lo = s_d[(l - 1) % 3], *mid = s_d[l % 3], *hi = s_d[(l + 1) % 3];
+        for (int rr = wv; rr < SX_TH; rr += 4) {
+            const int y = y0 + rr, x = x0 + lane;
+            if (y < S_BORDER || y >= h - S_BORDER) continue;             // wave-uniform
+            bool hit = false;
+            if (x >= S_BORDER && x < w - S_BORDER) {
+                const int ctr = (rr + 1) * SX_P + lane + 1;
+                const float val = mid[ctr];
+                if (fabsf(val) > 1.f) {
+                    bool ismax = val > 0, ismin = val < 0;
+#pragma unroll
+                    for (int dr = -1; dr <= 1; ++dr) {
+                        const int q = ctr + dr * SX_P;
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) {
+                            const float *pp = pl == 0 ? lo : pl == 1 ? mid : hi;
+                            const float a = pp[q - 1], b = pp[q], e = pp[q + 1];
+                            ismax = ismax && !(a > val) && !(b > val) && !(e > val);
+                            ismin = ismin && !(a < val) && !(b < val) && !(e < val);
+                        }
+                    }
+                    hit = ismax || ismin;
+                }
+            }
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) {
+                mk[((long long)(l - 1) * h + y) * dv.wpr[o] + (x0 >> 6)] = bal;
+                if (bal) atomicAdd(&bc[(l - 1) * (h - 2 * S_BORDER) + (y - S_BORDER)], __popcll(bal));
+            }
+        }
+        __syncthreads();
+    }
 }
 
-template <bool EMIT>
-__global__ __launch_bounds__(256) void sift_extrema_kernel(const float *__restrict__ dog, SiftDev dv, const SiftBand *__restrict__ bands,
-                                                            int *__restrict__ band_cnt, const int *__restrict__ band_off,
-                                                            unsigned *__restrict__ seeds)
+// exclusive scan of the band counters of one image (256 threads, a run of consecutive bands each)
+__global__ __launch_bounds__(256) void sift_band_scan_kernel(const int *__restrict__ band_cnt, int *__restrict__ band_off, int *__restrict__ nseeds, SiftDev dv)
 {
     __shared__ int s_wave[5];
-    const SiftBand bd = bands[blockIdx.x];
-    const int img = blockIdx.y, o = bd.o, w = dv.w[o];
-    const long long n = (long long)w * dv.h[o];
-    const float *d = dog + (long long)img * dv.dstride + dv.doff[o];
-    const int cols = w - 2 * S_BORDER, npx = (bd.r1 - bd.r0) * cols;
-    int base = EMIT ? band_off[img * dv.nbands + blockIdx.x] : 0;
-    int count = 0;
-    for (int p0 = 0; p0 < npx; p0 += 256) {
-        const int p = p0 + threadIdx.x;
-        bool hit = false; int r = 0, c = 0;
-        if (p < npx) { r = bd.r0 + p / cols; c = S_BORDER + p % cols; hit = sift_is_extremum(d, n, w, bd.l, r, c); }
-        int total;
-        const int ex = s_block_excl_scan(hit ? 1 : 0, s_wave, total);
-        if (EMIT && hit) {
-            const int idx = base + ex;
-            if (idx < dv.seed_cap) seeds[(long long)img * dv.seed_cap + idx] = ((unsigned)o << 28) | ((unsigned)bd.l << 26) | ((unsigned)r << 13) | (unsigned)c;
-        }
-        base += total; count += total;
-    }
-    if (!EMIT && threadIdx.x == 0) band_cnt[img * dv.nbands + blockIdx.x] = count;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int per = (dv.nbands + 255) / 256, b0 = tid * per, b1 = min(b0 + per, dv.nbands);
+    const int *bc = band_cnt + (long long)img * dv.nbands;
+    int sum = 0;
+    for (int b = b0; b < b1; ++b) sum += bc[b];
+    int total;
+    int acc = s_block_excl_scan(sum, s_wave, total);
+    int *bo = band_off + (long long)img * dv.nbands;
+    for (int b = b0; b < b1; ++b) { bo[b] = acc; acc += bc[b]; }
+    if (tid == 0) nseeds[img] = total < dv.seed_cap ? total : dv.seed_cap;
 }
 
-__global__ void sift_band_scan_kernel(const int *__restrict__ band_cnt, int *__restrict__ band_off, int *__restrict__ nseeds, SiftDev dv)
+// Pass 2: one wave per band (row) walks the row's mask words in order and writes the seeds at the
+// band's offset: raster order inside the row, bands in (octave, layer, row) order.
+__global__ __launch_bounds__(256) void sift_extrema_emit_kernel(const unsigned long long *__restrict__ mask, SiftDev dv,
+                                                                 const int *__restrict__ band_cnt, const int *__restrict__ band_off,
+                                                                 unsigned *__restrict__ seeds)
 {
-    const int img = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    int acc = 0;
-    for (int b = 0; b < dv.nbands; ++b) { band_off[img * dv.nbands + b] = acc; acc += band_cnt[img * dv.nbands + b]; }
-    nseeds[img] = acc < dv.seed_cap ? acc : dv.seed_cap;
+    const int lane = threadIdx.x & 63, band = blockIdx.x * 4 + (threadIdx.x >> 6), img = blockIdx.y;
+    if (band >= dv.nbands) return;
+    if (band_cnt[(long long)img * dv.nbands + band] == 0) return;
+    int o = 0;
+    for (int k = 1; k < dv.noct; ++k) if (band >= dv.band0[k]) o = k;
+    const int hv = dv.h[o] - 2 * S_BORDER, rem = band - dv.band0[o];
+    const int l = rem / hv + 1, r = rem - (l - 1) * hv + S_BORDER, wpr = dv.wpr[o];
+    const unsigned long long *words = mask + (long long)img * dv.bmstride + dv.bmoff[o] + ((long long)(l - 1) * dv.h[o] + r) * wpr;
+    int base = band_off[(long long)img * dv.nbands + band];
+    unsigned *out = seeds + (long long)img * dv.seed_cap;
+    for (int w0 = 0; w0 < wpr; w0 += 64) {
+        const int wi = w0 + lane;
+        unsigned long long m = wi < wpr ? words[wi] : 0ull;
+        const int cnt = __popcll(m);
+        int inc = cnt;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) { int v = __shfl_up(inc, s); if (lane >= s) inc += v; }
+        int idx = base + inc - cnt;
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (idx < dv.seed_cap) out[idx] = ((unsigned)o << 28) | ((unsigned)l << 26) | ((unsigned)r << 13) | (unsigned)(wi * 64 + b);
+            ++idx;
+        }
+        base += __shfl(inc, 63);
+    }
 }
 
 // ------------------------------------------------------- refine + orientation
@@ -760,22 +827,29 @@ int rpe_sift_create(rpe_handle *h)
     SCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_skern), kern, sizeof(kern)));
     SCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_sks), ks, sizeof(ks)));
     for (int i = 0; i < 6; ++i) S->ks[i] = ks[i];
-    // row bands for the extrema passes, in the oracle's enumeration order (octave, layer, row)
-    std::vector<SiftBand> bands;
-    for (int o = 0; o < dv.noct; ++o) {
-        if (dv.w[o] <= 2 * S_BORDER || dv.h[o] <= 2 * S_BORDER) continue;
-        int rb = 16384 / dv.w[o]; if (rb < 1) rb = 1;
-        for (int l = 1; l <= S_NOL; ++l)
-            for (int r = S_BORDER; r < dv.h[o] - S_BORDER; r += rb) {
-                int r1 = r + rb < dv.h[o] - S_BORDER ? r + rb : dv.h[o] - S_BORDER;
-                bands.push_back({(short)o, (short)l, r, r1});
-            }
+    // extrema scan: bands (one per row of every (octave, inner layer)) in the oracle's enumeration order, the hit
+    // mask layout and the tile list of the tiled first pass
+    std::vector<SiftXTile> xt;
+    {
+        int nb = 0; long long bo = 0;
+        for (int o = 0; o < 12; ++o) { dv.band0[o] = 0; dv.wpr[o] = 0; dv.bmoff[o] = 0; }
+        for (int o = 0; o < dv.noct; ++o) {
+            dv.band0[o] = nb; dv.wpr[o] = (dv.w[o] + 63) / 64; dv.bmoff[o] = bo;
+            if (dv.w[o] <= 2 * S_BORDER || dv.h[o] <= 2 * S_BORDER) continue;
+            nb += S_NOL * (dv.h[o] - 2 * S_BORDER);
+            bo += (long long)S_NOL * dv.h[o] * dv.wpr[o];
+            for (int y = 0; y < dv.h[o] - S_BORDER; y += SX_TH)
+                for (int x = 0; x < dv.w[o] - S_BORDER; x += SX_TW)
+                    if (y + SX_TH > S_BORDER && x + SX_TW > S_BORDER) xt.push_back({o, x, y});
+        }
+        dv.nbands = nb > 0 ? nb : 1; dv.bmstride = bo > 0 ? bo : 1;
     }
-    dv.nbands = (int)bands.size();
     const size_t NI = (size_t)h->n_img_cap;
     S->raw_pad = 16384;                       // sort capacity: candidates after the response prefilter
-    SCHK(hipMalloc(&S->d_bands, sizeof(SiftBand) * bands.size()));
-    SCHK(hipMemcpy(S->d_bands, bands.data(), sizeof(SiftBand) * bands.size(), hipMemcpyHostToDevice));
+    S->n_xtiles = (int)xt.size();
+    SCHK(hipMalloc(&S->d_xtiles, sizeof(SiftXTile) * (xt.size() ? xt.size() : 1)));
+    if (!xt.empty()) SCHK(hipMemcpy(S->d_xtiles, xt.data(), sizeof(SiftXTile) * xt.size(), hipMemcpyHostToDevice));
+    SCHK(hipMalloc(&S->d_xmask, sizeof(unsigned long long) * NI * dv.bmstride));
     SCHK(hipMalloc(&S->d_gauss, sizeof(float) * NI * dv.gstride));
     SCHK(hipMalloc(&S->d_dog, sizeof(float) * NI * dv.dstride));
     SCHK(hipMalloc(&S->d_tmp, sizeof(float) * NI * dv.tstride * 2));
@@ -798,7 +872,7 @@ void rpe_sift_destroy(rpe_handle *h)
 {
     RpeSiftState *S = h->sift;
     if (!S) return;
-    void *p[] = {S->d_gauss, S->d_dog, S->d_tmp, S->d_bands, S->d_band_cnt, S->d_band_off, S->d_seeds, S->d_nseeds, S->d_raw,
+    void *p[] = {S->d_gauss, S->d_dog, S->d_tmp, S->d_xtiles, S->d_xmask, S->d_band_cnt, S->d_band_off, S->d_seeds, S->d_nseeds, S->d_raw,
                  S->d_nraw, S->d_overflow, S->d_ncand, S->d_k0, S->d_k1, S->d_sidx, S->d_fin};
     for (void *q : p) if (q) hipFree(q);
     delete S;
@@ -862,11 +936,13 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
                       S->d_dog + dv.doff[o] + (i - 1) * pn, dv.dstride, w, hh, i, n);
     }
     // 3. seeds (count, scan, emit)
-    hipLaunchKernelGGL(sift_extrema_kernel<false>, dim3(dv.nbands, n), dim3(256), 0, h->stream, (const float *)S->d_dog, dv,
-                       (const SiftBand *)S->d_bands, S->d_band_cnt, (const int *)S->d_band_off, S->d_seeds);
-    hipLaunchKernelGGL(sift_band_scan_kernel, dim3(n), dim3(64), 0, h->stream, (const int *)S->d_band_cnt, S->d_band_off, S->d_nseeds, dv);
-    hipLaunchKernelGGL(sift_extrema_kernel<true>, dim3(dv.nbands, n), dim3(256), 0, h->stream, (const float *)S->d_dog, dv,
-                       (const SiftBand *)S->d_bands, S->d_band_cnt, (const int *)S->d_band_off, S->d_seeds);
+    hipMemsetAsync(S->d_band_cnt, 0, sizeof(int) * (size_t)n * dv.nbands, h->stream);
+    if (S->n_xtiles)
+        hipLaunchKernelGGL(sift_extrema_mask_kernel, dim3(S->n_xtiles, n), dim3(256), 0, h->stream, (const float *)S->d_dog, dv,
+                           (const SiftXTile *)S->d_xtiles, S->d_xmask, S->d_band_cnt);
+    hipLaunchKernelGGL(sift_band_scan_kernel, dim3(n), dim3(256), 0, h->stream, (const int *)S->d_band_cnt, S->d_band_off, S->d_nseeds, dv);
+    hipLaunchKernelGGL(sift_extrema_emit_kernel, dim3((dv.nbands + 3) / 4, n), dim3(256), 0, h->stream, (const unsigned long long *)S->d_xmask, dv,
+                       (const int *)S->d_band_cnt, (const int *)S->d_band_off, S->d_seeds);
     // 4. refine + orientation -> raw keypoints
     hipMemsetAsync(S->d_nraw, 0, sizeof(int) * n, h->stream);
     hipMemsetAsync(S->d_overflow, 0, sizeof(int) * n, h->stream);
