@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void sift_blur_col_kernel(const float *__restr
 // read every level again for the DoG).  Each lane accumulates 8 neighbouring outputs from a
 // register window of 8+2R values; tap order and accumulation order are the oracle's
 // (acc = 0; acc += k[i]*v[i], i ascending), so the f32 results are bit-identical.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int R>
 __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__restrict__ src, long long sstride, float *__restrict__ dst,
                                                                long long dstride, float *__restrict__ dog, long long dogstride,
@@ -140,27 +141,55 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
     if (ti >= ntiles) return;
     const int x0 = (ti % tcols) * 64, y0 = (ti / tcols) * 64;
     const float *s = src + (long long)blockIdx.y * sstride;
-    for (int i = tid; i < WIN * WIN; i += 256) {
-        const int r = i / WIN, c = i - r * WIN;
-        s_src[r * SP + c] = s[(size_t)s_refl(y0 + r - R, h) * w + s_refl(x0 + c - R, w)];
+    if (w > R && h > R) {
+        // window load, all requests in flight before the first LDS store: with one reflection being
+        // enough (n > R; coordinates past n-1+R only feed outputs outside the image and are clamped)
+        // the addresses are branch-free, so the loads are issued back to back instead of one
+        // HBM round trip per element
+        constexpr int NLD = (WIN * WIN + 255) / 256;
+        float stage[NLD];
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int i = min(tid + 256 * q, WIN * WIN - 1);
+            const int r = i / WIN, c = i - r * WIN;
+            int yy = min(max(y0 + r - R, -R), h - 1 + R), xx = min(max(x0 + c - R, -R), w - 1 + R);
+            yy = yy < 0 ? -yy : yy; yy = yy >= h ? 2 * h - 2 - yy : yy;
+            xx = xx < 0 ? -xx : xx; xx = xx >= w ? 2 * w - 2 - xx : xx;
+            stage[q] = s[(size_t)yy * w + xx];
+        }
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int i = tid + 256 * q;
+            const int r = i / WIN, c = i - r * WIN;
+            if (i < WIN * WIN) s_src[r * SP + c] = stage[q];
+        }
+    } else {
+        for (int i = tid; i < WIN * WIN; i += 256) {
+            const int r = i / WIN, c = i - r * WIN;
+            s_src[r * SP + c] = s[(size_t)s_refl(y0 + r - R, h) * w + s_refl(x0 + c - R, w)];
+        }
     }
     float k[KS];
 #pragma unroll
     for (int i = 0; i < KS; ++i) k[i] = c_skern[kid][i];
     __syncthreads();
+    // Both passes: a lane produces 8 outputs as 4 packed pairs (j, j+4); the tap window is held as
+    // pairs P[m] = (v[m], v[m+4]) so that every multiply and add is a v_pk_*_f32 (two IEEE f32
+    // operations per instruction, same rounding as the scalar ones: no contraction).
     // row pass: item = (window row, group of 8 columns)
     for (int it = tid; it < WIN * 8; it += 256) {
         const int r = it >> 3, g = it & 7;
         const float *row = s_src + r * SP + 8 * g;
-        float v[8 + 2 * R];
+        f32x2 P[4 + 2 * R];
 #pragma unroll
-        for (int i = 0; i < 8 + 2 * R; ++i) v[i] = row[i];
+        for (int m = 0; m < 4 + 2 * R; ++m) { P[m].x = row[m]; P[m].y = row[m + 4]; }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float acc = 0.f;
+        for (int j = 0; j < 4; ++j) {
+            f32x2 acc = {0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < KS; ++i) acc += k[i] * v[j + i];
-            s_tmp[r * 64 + 8 * g + j] = acc;
+            for (int i = 0; i < KS; ++i) { const f32x2 kk = {k[i], k[i]}; acc += kk * P[j + i]; }
+            s_tmp[r * 64 + 8 * g + j] = acc.x;
+            s_tmp[r * 64 + 8 * g + j + 4] = acc.y;
         }
     }
     __syncthreads();
@@ -169,19 +198,23 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
     for (int it = tid; it < 64 * 8; it += 256) {
         const int c = it & 63, g = it >> 6;
         const float *col = s_tmp + (8 * g) * 64 + c;
-        float v[8 + 2 * R];
+        f32x2 P[4 + 2 * R];
 #pragma unroll
-        for (int i = 0; i < 8 + 2 * R; ++i) v[i] = col[i * 64];
+        for (int m = 0; m < 4 + 2 * R; ++m) { P[m].x = col[m * 64]; P[m].y = col[(m + 4) * 64]; }
         const int x = x0 + c;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float acc = 0.f;
+        for (int j = 0; j < 4; ++j) {
+            f32x2 acc = {0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < KS; ++i) acc += k[i] * v[j + i];
-            const int y = y0 + 8 * g + j;
-            if (x < w && y < h) {
-                dst[ob + (size_t)y * w + x] = acc;
-                if (dog) dog[db + (size_t)y * w + x] = acc - s_src[(8 * g + j + R) * SP + c + R];
+            for (int i = 0; i < KS; ++i) { const f32x2 kk = {k[i], k[i]}; acc += kk * P[j + i]; }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int yy = 8 * g + j + 4 * hh, y = y0 + yy;
+                const float a = hh ? acc.y : acc.x;
+                if (x < w && y < h) {
+                    dst[ob + (size_t)y * w + x] = a;
+                    if (dog) dog[db + (size_t)y * w + x] = a - s_src[(yy + R) * SP + c + R];
+                }
             }
         }
     }
