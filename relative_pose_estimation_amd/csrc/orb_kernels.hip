@@ -73,11 +73,19 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
     int oy[4], b1[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) { int y = min(y0 + tyb + 16 * rr, D.h - 1); oy[rr] = yo[y]; b1[rr] = ya[y]; }
-    for (int i = tid; i < PYR_ROWS * PYR_DW; i += 256) {
-        int r = i / PYR_DW, c = i - r * PYR_DW;
-        int y = min(sy0 + r, S.h - 1);
-        int x = min(a0 + 4 * c, S.pitch - 4);
-        s_src[i] = *(const unsigned *)(src + (long long)y * S.pitch + x);
+    {   // all window loads in flight before the first LDS store (one HBM round trip, not six)
+        constexpr int NLD = (PYR_ROWS * PYR_DW + 255) / 256;
+        unsigned stage[NLD];
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int i = min(tid + 256 * q, PYR_ROWS * PYR_DW - 1);
+            const int r = i / PYR_DW, c = i - r * PYR_DW;
+            const int y = min(sy0 + r, S.h - 1);
+            const int x = min(a0 + 4 * c, S.pitch - 4);
+            stage[q] = *(const unsigned *)(src + (long long)y * S.pitch + x);
+        }
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) { const int i = tid + 256 * q; if (i < PYR_ROWS * PYR_DW) s_src[i] = stage[q]; }
     }
     __syncthreads();
     if (x4 >= D.pitch) return;
@@ -168,11 +176,19 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
     const uint8_t *src = pyr + ibase;
     if (tid == 0) s_ncand = 0;
     s_hist[tid] = 0;
-    for (int i = tid; i < 72 * 18; i += 256) {
-        int r = i / 18, c = i - r * 18;
-        int y = min(max(y0 - 4 + r, 0), hgt - 1);
-        int x = min(max(x0 - 4 + 4 * c, 0), pitch - 4);
-        s_in[i] = *(const unsigned *)(src + (long long)y * pitch + x);
+    {   // all tile loads in flight before the first LDS store
+        constexpr int NLD = (72 * 18 + 255) / 256;
+        unsigned stage[NLD];
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int i = min(tid + 256 * q, 72 * 18 - 1);
+            const int r = i / 18, c = i - r * 18;
+            const int y = min(max(y0 - 4 + r, 0), hgt - 1);
+            const int x = min(max(x0 - 4 + 4 * c, 0), pitch - 4);
+            stage[q] = *(const unsigned *)(src + (long long)y * pitch + x);
+        }
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) { const int i = tid + 256 * q; if (i < 72 * 18) s_in[i] = stage[q]; }
     }
     for (int i = tid; i < FS_ROWS * 18; i += 256) s_sc[i] = 0;
     for (int i = tid; i < 64 * 16; i += 256) s_nms[i] = 0;
@@ -600,10 +616,16 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
     unsigned *raw = s_raw[wv], *hb = s_hb[wv];
     if (active) {
         const uint8_t *src = pyr + (long long)img * lay.stride + L.off + (long long)(y0 - KP_R) * pitch + xal;
-        for (int i = lane; i < KP_ROWS * KP_RAW_DW; i += 64) {
-            int r = i / KP_RAW_DW, c = i - r * KP_RAW_DW;
-            raw[i] = *(const unsigned *)(src + (long long)r * pitch + 4 * c);
+        constexpr int NLD = (KP_ROWS * KP_RAW_DW + 63) / 64;
+        unsigned stage[NLD];
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int i = min(lane + 64 * q, KP_ROWS * KP_RAW_DW - 1);
+            const int r = i / KP_RAW_DW, c = i - r * KP_RAW_DW;
+            stage[q] = *(const unsigned *)(src + (long long)r * pitch + 4 * c);
         }
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) { const int i = lane + 64 * q; if (i < KP_ROWS * KP_RAW_DW) raw[i] = stage[q]; }
     }
     __syncthreads();
     float a = 1.f, b = 0.f;
