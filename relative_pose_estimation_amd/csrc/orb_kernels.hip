@@ -394,26 +394,40 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const uint8_t *_
     const int ccap = L.ccap;
     unsigned *out = cand_xy + (long long)img * lay.cand_total + L.cand_off;
     int base = 0;
-    for (int c0 = 0; c0 < nbytes; c0 += 4096) {
-        int pos = c0 + tid * 16;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (pos < nbytes) v = *(const uint4 *)(src + pos);
-        unsigned wds[4] = {v.x, v.y, v.z, v.w};
-        int cnt = 0;
-        if ((v.x | v.y | v.z | v.w) != 0) {
+    // 64 consecutive bytes per lane and step (4 x 16-B loads in flight): a quarter of the
+    // dependent HBM round trips / block scans of a 16-B-per-lane scan, same raster order
+    for (int c0 = 0; c0 < nbytes; c0 += 16384) {
+        const int pos = c0 + tid * 64;
+        uint4 v[4];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) cnt += (int)((wds[k >> 2] >> (8 * (k & 3))) & 255) >= tau;
+        for (int q = 0; q < 4; ++q) {
+            v[q] = make_uint4(0, 0, 0, 0);
+            if (pos + 16 * q < nbytes) v[q] = *(const uint4 *)(src + pos + 16 * q);
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned wds[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+            if ((v[q].x | v[q].y | v[q].z | v[q].w) != 0) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) cnt += (int)((wds[k >> 2] >> (8 * (k & 3))) & 255) >= tau;
+            }
         }
         int total;
         int ex = block_excl_scan(cnt, s_wave, total);
         if (cnt) {
             int o = base + ex;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                int b = (int)((wds[k >> 2] >> (8 * (k & 3))) & 255);
-                if (b >= tau) {
-                    if (o < ccap) { int p = pos + k; int y = p / L.pitch; int x = p - y * L.pitch; out[o] = ((unsigned)(y + row0) << 16) | (unsigned)x; }
-                    ++o;
+            for (int q = 0; q < 4; ++q) {
+                const unsigned wds[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+                if ((v[q].x | v[q].y | v[q].z | v[q].w) == 0) continue;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    int b = (int)((wds[k >> 2] >> (8 * (k & 3))) & 255);
+                    if (b >= tau) {
+                        if (o < ccap) { int p = pos + 16 * q + k; int y = p / L.pitch; int x = p - y * L.pitch; out[o] = ((unsigned)(y + row0) << 16) | (unsigned)x; }
+                        ++o;
+                    }
                 }
             }
         }

@@ -256,12 +256,23 @@ __device__ __forceinline__ int s_block_excl_scan(int v, int *s_wave, int &total)
 }
 
 // Pass 1 (tiled, any order): 26-neighbour test of the three inner DoG layers of a 64x32 tile.  The
-// five layers roll through three LDS planes (each DoG value leaves HBM once per tile instead of up to
-// 27 times through the caches), one wave owns a row: the hit flags of a row are a 64-bit ballot =
+// five layers roll through three LDS planes (each DoG value leaves HBM once per tile).  "No
+// neighbour is greater" <=> val >= max of the 3x3x3 block (val itself included), and that max is
+// separable: per lane (= column) the max/min over 3 layers of one row (3 LDS reads per new row),
+// rolled over 3 rows, then across columns with two DPP wave shifts; the tile's halo columns are
+// read by broadcast.  A wave owns 8 consecutive rows; the hit flags of a row are a 64-bit ballot =
 // one mask word, its popcount goes to the row's band counter (integer atomic: deterministic).
 #define SX_TW 64
 #define SX_TH 32
 #define SX_P 67
+__device__ __forceinline__ float dpp_wave_shr1(float v)     // lane i <- lane i-1 (lane 0 keeps v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_wave_shl1(float v)     // lane i <- lane i+1 (lane 63 keeps v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
+}
 __global__ __launch_bounds__(256) void sift_extrema_mask_kernel(const float *__restrict__ dog, SiftDev dv, const SiftXTile *__restrict__ tiles,
                                                                  unsigned long long *__restrict__ mask, int *__restrict__ band_cnt)
 {
@@ -271,49 +282,69 @@ __global__ __launch_bounds__(256) void sift_extrema_mask_kernel(const float *__r
     const long long n = (long long)w * h;
     const float *d = dog + (long long)img * dv.dstride + dv.doff[o];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    auto load = [&](int layer, int slot) {
+    constexpr int NEL = (SX_TH + 2) * (SX_TW + 2), NLD = (NEL + 255) / 256;
+    float stage[NLD];
+    auto fetch = [&](int layer) {               // all loads of a layer in flight
         const float *src = d + layer * n;
-        for (int i = tid; i < (SX_TH + 2) * (SX_TW + 2); i += 256) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int i = min(tid + 256 * q, NEL - 1);
             const int r = i / (SX_TW + 2), c = i - r * (SX_TW + 2);
             const int y = min(max(y0 - 1 + r, 0), h - 1), x = min(max(x0 - 1 + c, 0), w - 1);
-            s_d[slot][r * SX_P + c] = src[(size_t)y * w + x];
+            stage[q] = src[(size_t)y * w + x];
         }
     };
-    load(0, 0); load(1, 1);
+    auto commit = [&](int slot) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int i = tid + 256 * q;
+            const int r = i / (SX_TW + 2), c = i - r * (SX_TW + 2);
+            if (i < NEL) s_d[slot][r * SX_P + c] = stage[q];
+        }
+    };
+    fetch(0); commit(0);
+    fetch(1); commit(1);
+    fetch(2);
     unsigned long long *mk = mask + (long long)img * dv.bmstride + dv.bmoff[o];
     int *bc = band_cnt + (long long)img * dv.nbands + dv.band0[o];
+    const int hcol = lane < 32 ? 0 : SX_TW + 1;            // halo column this lane can stand in for
     for (int l = 1; l <= S_NOL; ++l) {
-        load(l + 1, (l + 1) % 3);
+        commit((l + 1) % 3);
         __syncthreads();
+        if (l < S_NOL) fetch(l + 2);                        // next layer's loads fly during the tests
         const float *lo = s_d[(l - 1) % 3], *mid = s_d[l % 3], *hi = s_d[(l + 1) % 3];
-        for (int rr = wv; rr < SX_TH; rr += 4) {
-            const int y = y0 + rr, x = x0 + lane;
-            if (y < S_BORDER || y >= h - S_BORDER) continue;             // wave-uniform
-            bool hit = false;
-            if (x >= S_BORDER && x < w - S_BORDER) {
-                const int ctr = (rr + 1) * SX_P + lane + 1;
-                const float val = mid[ctr];
-                if (fabsf(val) > 1.f) {
-                    bool ismax = val > 0, ismin = val < 0;
+        // rolling per-row layer max/min: own column and halo column
+        float pmx[3], pmn[3], hmx[3], hmn[3];
+        auto rowmm = [&](int lr, float &mx, float &mn, float &hx, float &hn) {       // lr = LDS row
+            const int q = lr * SX_P + lane + 1, qh = lr * SX_P + hcol;
+            const float a = lo[q], b = mid[q], c = hi[q];
+            mx = fmaxf(fmaxf(a, b), c); mn = fminf(fminf(a, b), c);
+            const float ah = lo[qh], bh = mid[qh], ch = hi[qh];
+            hx = fmaxf(fmaxf(ah, bh), ch); hn = fminf(fminf(ah, bh), ch);
+        };
+        const int rb = 8 * wv;                              // first output row of this wave (tile-relative)
+        rowmm(rb, pmx[0], pmn[0], hmx[0], hmn[0]);
+        rowmm(rb + 1, pmx[1], pmn[1], hmx[1], hmn[1]);
 #pragma unroll
-                    for (int dr = -1; dr <= 1; ++dr) {
-                        const int q = ctr + dr * SX_P;
-#pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) {
-                            const float *pp = pl == 0 ? lo : pl == 1 ? mid : hi;
-                            const float a = pp[q - 1], b = pp[q], e = pp[q + 1];
-                            ismax = ismax && !(a > val) && !(b > val) && !(e > val);
-                            ismin = ismin && !(a < val) && !(b < val) && !(e < val);
-                        }
-                    }
-                    hit = ismax || ismin;
-                }
-            }
+        for (int k = 0; k < 8; ++k) {
+            const int rr = rb + k, y = y0 + rr, x = x0 + lane;
+            rowmm(rr + 2, pmx[2], pmn[2], hmx[2], hmn[2]);
+            const float cmx = fmaxf(fmaxf(pmx[0], pmx[1]), pmx[2]), cmn = fminf(fminf(pmn[0], pmn[1]), pmn[2]);
+            const float hx = fmaxf(fmaxf(hmx[0], hmx[1]), hmx[2]), hn = fminf(fminf(hmn[0], hmn[1]), hmn[2]);
+            float lmx = dpp_wave_shr1(cmx), lmn = dpp_wave_shr1(cmn), rmx = dpp_wave_shl1(cmx), rmn = dpp_wave_shl1(cmn);
+            if (lane == 0) { lmx = hx; lmn = hn; }
+            if (lane == 63) { rmx = hx; rmn = hn; }
+            const float M = fmaxf(fmaxf(lmx, cmx), rmx), m = fminf(fminf(lmn, cmn), rmn);
+            const float val = mid[(rr + 1) * SX_P + lane + 1];
+            const bool hit = y >= S_BORDER && y < h - S_BORDER && x >= S_BORDER && x < w - S_BORDER && fabsf(val) > 1.f &&
+                             ((val > 0.f && val >= M) || (val < 0.f && val <= m));
             const unsigned long long bal = __ballot(hit);
-            if (lane == 0) {
+            if (lane == 0 && y >= S_BORDER && y < h - S_BORDER) {
                 mk[((long long)(l - 1) * h + y) * dv.wpr[o] + (x0 >> 6)] = bal;
                 if (bal) atomicAdd(&bc[(l - 1) * (h - 2 * S_BORDER) + (y - S_BORDER)], __popcll(bal));
             }
+            pmx[0] = pmx[1]; pmx[1] = pmx[2]; pmn[0] = pmn[1]; pmn[1] = pmn[2];
+            hmx[0] = hmx[1]; hmx[1] = hmx[2]; hmn[0] = hmn[1]; hmn[1] = hmn[2];
         }
         __syncthreads();
     }
