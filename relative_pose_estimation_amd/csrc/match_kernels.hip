@@ -145,69 +145,85 @@ __device__ __forceinline__ unsigned dot128_u8(const uint4 *q, const uint4 (&t)[8
     return acc;
 }
 
-__global__ __launch_bounds__(256) void match_l2_kernel(const uint8_t *__restrict__ desc, const int *__restrict__ kp_count,
-                                                        const float2 *__restrict__ kp_pt, int img2_base, int kcap, int max_matches,
-                                                        int *__restrict__ m_q, int *__restrict__ m_t, float *__restrict__ m_d,
-                                                        int *__restrict__ m_n, float2 *__restrict__ pts1, float2 *__restrict__ pts2)
+// Kernel 1: workgroup = (256 train descriptors, pair).  Every train elects its nearest query over
+// all query tiles; the election lands in HBM through a packed 64-bit atomicMin per query
+// (integer atomics: order independent).  Splitting a pair over its train chunks gives kcap/256 times
+// more workgroups than one workgroup per pair (32-pair HD sub-batches left 7/8 of the CUs idle).
+__global__ __launch_bounds__(256) void match_l2_nearest_kernel(const uint8_t *__restrict__ desc, const int *__restrict__ kp_count,
+                                                                int img2_base, int kcap, unsigned long long *__restrict__ best)
 {
-    extern __shared__ uint4 s_dyn[];
-    uint4 *s_q = s_dyn;                                                        // L2_QTILE x 8 uint4 = 32 KB (later: sort keys)
-    unsigned *s_qn = (unsigned *)(s_dyn + L2_QTILE * 8);                       // |q|^2 of the tile
-    unsigned long long *s_best = (unsigned long long *)(s_qn + L2_QTILE);      // kcap entries
+    __shared__ uint4 s_q[L2_QTILE * 8];                                         // 32 KB
+    __shared__ unsigned s_qn[L2_QTILE];                                         // |q|^2 of the tile
+    const int tid = threadIdx.x, pair = blockIdx.y, tc = blockIdx.x * 256;
+    const int img1 = pair, img2 = img2_base + pair;
+    const int n1 = min(kp_count[img1], kcap), n2 = min(kp_count[img2], kcap);
+    if (tc >= n2 || n1 <= 0) return;
+    const uint4 *d1 = (const uint4 *)(desc + (long long)img1 * kcap * L2_DIM);
+    const uint4 *d2 = (const uint4 *)(desc + (long long)img2 * kcap * L2_DIM);
+    const int j = tc + tid;
+    const bool valid = j < n2;
+    uint4 t[8];
+    unsigned tn = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        t[k] = valid ? d2[8 * j + k] : make_uint4(0, 0, 0, 0);
+        tn = __builtin_amdgcn_udot4(t[k].x, t[k].x, tn, false); tn = __builtin_amdgcn_udot4(t[k].y, t[k].y, tn, false);
+        tn = __builtin_amdgcn_udot4(t[k].z, t[k].z, tn, false); tn = __builtin_amdgcn_udot4(t[k].w, t[k].w, tn, false);
+    }
+    float bestd = __builtin_inff();
+    int besti = -1;
+    for (int qt = 0; qt < n1; qt += L2_QTILE) {
+        const int nq = min(L2_QTILE, n1 - qt);
+        __syncthreads();
+        {
+            uint4 stage[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int idx = tid + 256 * q; stage[q] = idx < nq * 8 ? d1[8 * qt + idx] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s_q[tid + 256 * q] = stage[q];
+        }
+        __syncthreads();
+        if (tid < nq) {
+            unsigned qn = 0;
+            for (int k = 0; k < 8; ++k) {
+                const uint4 a = s_q[8 * tid + k];
+                qn = __builtin_amdgcn_udot4(a.x, a.x, qn, false); qn = __builtin_amdgcn_udot4(a.y, a.y, qn, false);
+                qn = __builtin_amdgcn_udot4(a.z, a.z, qn, false); qn = __builtin_amdgcn_udot4(a.w, a.w, qn, false);
+            }
+            s_qn[tid] = qn;
+        }
+        __syncthreads();
+        for (int i = 0; i < nq; ++i) {
+            const unsigned ab = dot128_u8(s_q + 8 * i, t);
+            const float d = sqrtf((float)(s_qn[i] + tn - 2u * ab));
+            if (d < bestd) { bestd = d; besti = qt + i; }
+        }
+    }
+    if (valid && besti >= 0)
+        atomicMin(&best[(long long)pair * kcap + besti], ((unsigned long long)__float_as_uint(bestd) << 18) | (unsigned long long)j);
+}
+
+// Kernel 2: workgroup = pair: stable sort of the elected (distance, queryIdx) keys, first max_matches, point gather.
+__global__ __launch_bounds__(256) void match_l2_select_kernel(const unsigned long long *__restrict__ best, const int *__restrict__ kp_count,
+                                                               const float2 *__restrict__ kp_pt, int img2_base, int kcap, int max_matches,
+                                                               int *__restrict__ m_q, int *__restrict__ m_t, float *__restrict__ m_d,
+                                                               int *__restrict__ m_n, float2 *__restrict__ pts1, float2 *__restrict__ pts2)
+{
+    extern __shared__ unsigned long long s_key[];          // sortP <= 4096 keys
     __shared__ int s_valid;
     const int tid = threadIdx.x, pair = blockIdx.x;
     const int img1 = pair, img2 = img2_base + pair;
-    const int n1 = min(kp_count[img1], kcap), n2 = min(kp_count[img2], kcap);
-    for (int i = tid; i < n1; i += 256) s_best[i] = ~0ull;
+    const int n1 = min(kp_count[img1], kcap);
+    const unsigned long long *bp = best + (long long)pair * kcap;
     if (tid == 0) s_valid = 0;
-    const uint4 *d1 = (const uint4 *)(desc + (long long)img1 * kcap * L2_DIM);
-    const uint4 *d2 = (const uint4 *)(desc + (long long)img2 * kcap * L2_DIM);
-    for (int tc = 0; tc < n2; tc += 256) {
-        const int j = tc + tid;
-        const bool valid = j < n2;
-        uint4 t[8];
-        unsigned tn = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            t[k] = valid ? d2[8 * j + k] : make_uint4(0, 0, 0, 0);
-            tn = __builtin_amdgcn_udot4(t[k].x, t[k].x, tn, false); tn = __builtin_amdgcn_udot4(t[k].y, t[k].y, tn, false);
-            tn = __builtin_amdgcn_udot4(t[k].z, t[k].z, tn, false); tn = __builtin_amdgcn_udot4(t[k].w, t[k].w, tn, false);
-        }
-        float bestd = __builtin_inff();
-        int besti = -1;
-        for (int qt = 0; qt < n1; qt += L2_QTILE) {
-            const int nq = min(L2_QTILE, n1 - qt);
-            __syncthreads();
-            for (int idx = tid; idx < nq * 8; idx += 256) s_q[idx] = d1[8 * qt + idx];
-            __syncthreads();
-            if (tid < nq) {
-                unsigned qn = 0;
-                for (int k = 0; k < 8; ++k) {
-                    const uint4 a = s_q[8 * tid + k];
-                    qn = __builtin_amdgcn_udot4(a.x, a.x, qn, false); qn = __builtin_amdgcn_udot4(a.y, a.y, qn, false);
-                    qn = __builtin_amdgcn_udot4(a.z, a.z, qn, false); qn = __builtin_amdgcn_udot4(a.w, a.w, qn, false);
-                }
-                s_qn[tid] = qn;
-            }
-            __syncthreads();
-            for (int i = 0; i < nq; ++i) {
-                const unsigned ab = dot128_u8(s_q + 8 * i, t);
-                const float d = sqrtf((float)(s_qn[i] + tn - 2u * ab));
-                if (d < bestd) { bestd = d; besti = qt + i; }
-            }
-        }
-        if (valid && besti >= 0)
-            atomicMin(&s_best[besti], ((unsigned long long)__float_as_uint(bestd) << 18) | (unsigned long long)j);
-    }
     __syncthreads();
     int sortP = 64;
     while (sortP < n1) sortP <<= 1;
-    unsigned long long *s_key = (unsigned long long *)s_q;     // sortP <= 4096 keys of 8 bytes
     int myvalid = 0;
     for (int i = tid; i < sortP; i += 256) {
         unsigned long long key = ~0ull;
         if (i < n1) {
-            unsigned long long b = s_best[i];
+            unsigned long long b = bp[i];
             if (b != ~0ull) { key = ((b >> 18) << 16) | (unsigned long long)i; ++myvalid; }
         }
         s_key[i] = key;
@@ -230,7 +246,7 @@ __global__ __launch_bounds__(256) void match_l2_kernel(const uint8_t *__restrict
     for (int r = tid; r < nm; r += 256) {
         unsigned long long key = s_key[r];
         int i = (int)(key & 0xFFFF);
-        int j = (int)(s_best[i] & 0x3FFFF);
+        int j = (int)(bp[i] & 0x3FFFF);
         long long o = (long long)pair * max_matches + r;
         m_q[o] = i; m_t[o] = j; m_d[o] = __uint_as_float((unsigned)(key >> 16));
         pts1[o] = kp_pt[(long long)img1 * kcap + i];
@@ -242,8 +258,13 @@ __global__ __launch_bounds__(256) void match_l2_kernel(const uint8_t *__restrict
 void rpe_launch_match_l2(rpe_handle *h, int B)
 {
     const int kcap = h->lay.kcap;
-    size_t lds = (size_t)L2_QTILE * 128 + (size_t)L2_QTILE * 4 + (size_t)kcap * 8;
-    hipLaunchKernelGGL(match_l2_kernel, dim3(B), dim3(256), lds, h->stream,
-                       h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches,
+    const int img2_base = h->img2_base ? h->img2_base : B;
+    hipMemsetAsync(h->d_m_best, 0xFF, sizeof(unsigned long long) * (size_t)B * kcap, h->stream);
+    hipLaunchKernelGGL(match_l2_nearest_kernel, dim3((kcap + 255) / 256, B), dim3(256), 0, h->stream,
+                       h->d_desc, h->d_kp_count, img2_base, kcap, h->d_m_best);
+    int sortP = 64;
+    while (sortP < kcap) sortP <<= 1;
+    hipLaunchKernelGGL(match_l2_select_kernel, dim3(B), dim3(256), sizeof(unsigned long long) * (size_t)sortP, h->stream,
+                       (const unsigned long long *)h->d_m_best, h->d_kp_count, h->d_kp_pt, img2_base, kcap, h->cfg.max_matches,
                        h->d_m_q, h->d_m_t, (float *)h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
 }

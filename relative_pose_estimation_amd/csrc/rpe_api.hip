@@ -256,6 +256,7 @@ static int alloc_workspace(rpe_handle *h)
     HIPCHK(h, hipMemset(h->d_kp_count, 0, NI * sizeof(int)));
     DM(h, h->d_m_q, B * mm); DM(h, h->d_m_t, B * mm); DM(h, h->d_m_d, B * mm); DM(h, h->d_m_n, B);
     DM(h, h->d_pts1, B * mm); DM(h, h->d_pts2, B * mm);
+    if (h->cfg.norm_type == RPE_NORM_L2) DM(h, h->d_m_best, B * L.kcap);
     DM(h, h->d_n1, B * mm); DM(h, h->d_n2, B * mm);
     DM(h, h->d_rstate, B); DM(h, h->d_found, B);
     DM(h, h->d_models, B * RPE_RANSAC_MAXCHUNK * RPE_MAX_MODELS * 9);
@@ -322,7 +323,7 @@ extern "C" void rpe_destroy(rpe_handle *h)
                     h->d_hist, h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_angle,
                     h->d_kp_pt, h->d_kp_cs, h->d_kp_count, h->d_desc, h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2,
                     h->d_subsets, h->d_nit_denom, h->d_nit_round, h->d_rstate, h->d_n1, h->d_n2, h->d_found, h->d_models, h->d_hyp, h->d_counts,
-                    h->d_nmodels, h->d_mask, h->d_R, h->d_t, h->d_E, h->d_inliers, h->d_status, h->d_K};
+                    h->d_nmodels, h->d_mask, h->d_R, h->d_t, h->d_E, h->d_inliers, h->d_status, h->d_K, h->d_m_best};
     for (void *p : ptrs) if (p) hipFree(p);
     for (void *p : h->user_allocs) hipFree(p);
     for (int i = 0; i <= RPE_STAGE_COUNT; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);

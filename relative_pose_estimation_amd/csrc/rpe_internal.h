@@ -84,6 +84,7 @@ struct rpe_handle {
     uint8_t *d_desc = nullptr;        // [img][kcap][32]
     // matching
     int *d_m_q = nullptr, *d_m_t = nullptr, *d_m_d = nullptr, *d_m_n = nullptr;
+    unsigned long long *d_m_best = nullptr;   // L2 matcher: [pair][kcap] packed (f32 dist bits << 18 | trainIdx) of the best elector
     float2 *d_pts1 = nullptr, *d_pts2 = nullptr;   // [pair][max_matches]
     // RANSAC
     unsigned short *d_subsets = nullptr;  // [M 0..max_matches][iters][5]

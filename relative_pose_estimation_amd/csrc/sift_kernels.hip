@@ -738,6 +738,7 @@ __global__ __launch_bounds__(256) void sift_describe_kernel(const float *__restr
 {
     __shared__ float s_part[4][360][8];
     __shared__ float s_hist[4][360];
+    __shared__ float s_stage[4][64 * 9];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int kidx = blockIdx.x * 4 + wv, img = blockIdx.y;
     if (kidx >= kp_count[img]) return;
@@ -762,6 +763,7 @@ __global__ __launch_bounds__(256) void sift_describe_kernel(const float *__restr
     if (radius > rmax) radius = rmax;
     cos_t /= hist_width; sin_t /= hist_width;
     volatile float (*part)[8] = s_part[wv];
+    volatile float *stg = s_stage[wv];
     for (int i = lane; i < 360 * 8; i += 64) ((volatile float *)part)[i] = 0.f;
     const int side = 2 * radius + 1, nsamp = side * side;
     for (int k0 = 0; k0 < nsamp; k0 += 64) {
@@ -794,18 +796,25 @@ __global__ __launch_bounds__(256) void sift_describe_kernel(const float *__restr
                 idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
             }
         }
+        // Accumulation: sample k adds its 8 trilinear corners to slot (k & 7) of 8 distinct bins, and every
+        // (bin, slot) accumulator must see its samples in ascending k.  Lane (s, q) = (slot, corner) walks the
+        // 8 samples of this batch that use slot s in ascending order: lanes differ in slot or in bin, so the 64
+        // read-modify-writes of a step never collide and the per-accumulator order is the sequential one.
+        stg[lane * 9] = valid ? __int_as_float(idx) : __int_as_float(-1);
+        stg[lane * 9 + 1] = v000; stg[lane * 9 + 2] = v001; stg[lane * 9 + 3] = v010; stg[lane * 9 + 4] = v011;
+        stg[lane * 9 + 5] = v100; stg[lane * 9 + 6] = v101; stg[lane * 9 + 7] = v110; stg[lane * 9 + 8] = v111;
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int sl = lane & 7, q = lane >> 3;
+            const int qoff = (q & 1) + ((q >> 1) & 1) * (n + 2) + (q >> 2) * (d + 2) * (n + 2);
 #pragma unroll
-        for (int rd = 0; rd < 8; ++rd) {
-            if ((lane >> 3) == rd && valid) {
-                const int L = lane & 7;
-                part[idx][L] = part[idx][L] + v000; part[idx + 1][L] = part[idx + 1][L] + v001;
-                part[idx + (n + 2)][L] = part[idx + (n + 2)][L] + v010; part[idx + (n + 3)][L] = part[idx + (n + 3)][L] + v011;
-                part[idx + (d + 2) * (n + 2)][L] = part[idx + (d + 2) * (n + 2)][L] + v100;
-                part[idx + (d + 2) * (n + 2) + 1][L] = part[idx + (d + 2) * (n + 2) + 1][L] + v101;
-                part[idx + (d + 3) * (n + 2)][L] = part[idx + (d + 3) * (n + 2)][L] + v110;
-                part[idx + (d + 3) * (n + 2) + 1][L] = part[idx + (d + 3) * (n + 2) + 1][L] + v111;
+            for (int st = 0; st < 8; ++st) {
+                const int kl = sl + 8 * st;
+                const int id = __float_as_int(stg[kl * 9]);
+                const float v = stg[kl * 9 + 1 + q];
+                if (id >= 0) part[id + qoff][sl] = part[id + qoff][sl] + v;
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
         }
     }
     volatile float *hist = s_hist[wv];
