@@ -56,6 +56,7 @@ struct RpeSiftState {
     unsigned *d_seeds = nullptr; int *d_nseeds = nullptr; // [img][seed_cap], [img]
     float *d_raw = nullptr;                                // [img][raw_cap][6]: x y size angle response octave(bits)
     int *d_nraw = nullptr, *d_overflow = nullptr, *d_ncand = nullptr;
+    float *d_surv = nullptr; int *d_nsurv = nullptr;        // [img][seed_cap][SURV_W] refined seeds, [img]
     unsigned long long *d_k0 = nullptr, *d_k1 = nullptr; unsigned *d_sidx = nullptr; // sort keys [img][raw_pad]
     int raw_pad = 0;
     int ks[6] = {0, 0, 0, 0, 0, 0};                      // tap counts of c_skern
@@ -472,28 +473,46 @@ __device__ static bool sift_adjust(const DogCtx &c, int &layer, int &r, int &x, 
     return true;
 }
 
-__global__ __launch_bounds__(256) void sift_refine_kernel(const float *__restrict__ gauss, const float *__restrict__ dog, SiftDev dv,
+// Refinement is split in two so that neither half idles lanes: adjustLocalExtrema is a serial
+// per-seed computation (one LANE per seed; most seeds die here on the contrast / edge tests), the
+// orientation histogram is a per-survivor reduction (one WAVE per survivor).  Survivors and raw
+// keypoints are appended through integer atomics; their order is irrelevant (sorted afterwards).
+#define SURV_W 8        // floats per survivor record: packed(o,l,r,c), xi, xr, xc, contr
+__global__ __launch_bounds__(256) void sift_adjust_kernel(const float *__restrict__ dog, SiftDev dv,
                                                            const unsigned *__restrict__ seeds, const int *__restrict__ nseeds,
+                                                           float *__restrict__ surv, int *__restrict__ nsurv)
+{
+    const int sidx = blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
+    if (sidx >= nseeds[img]) return;
+    const unsigned sd = seeds[(long long)img * dv.seed_cap + sidx];
+    const int o = sd >> 28;
+    int l = (sd >> 26) & 3, r = (sd >> 13) & 0x1FFF, c = sd & 0x1FFF;
+    const int w = dv.w[o], h = dv.h[o];
+    DogCtx dc = {dog + (long long)img * dv.dstride + dv.doff[o], (long long)w * h, w, h};
+    float xi = 0, xr = 0, xc = 0, contr = 0;
+    if (!sift_adjust(dc, l, r, c, xi, xr, xc, contr)) return;
+    const int slot = atomicAdd(&nsurv[img], 1);               // <= nseeds <= seed_cap
+    float *q = surv + ((long long)img * dv.seed_cap + slot) * SURV_W;
+    q[0] = __int_as_float((int)(((unsigned)o << 28) | ((unsigned)l << 26) | ((unsigned)r << 13) | (unsigned)c));
+    q[1] = xi; q[2] = xr; q[3] = xc; q[4] = contr;
+}
+
+__global__ __launch_bounds__(256) void sift_orient_kernel(const float *__restrict__ gauss, SiftDev dv,
+                                                           const float *__restrict__ surv, const int *__restrict__ nsurv,
                                                            float *__restrict__ raw, int *__restrict__ nraw, int *__restrict__ overflow)
 {
     __shared__ float s_part[4][S_BINS][8];
     __shared__ float s_hist[4][S_BINS + 4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int sidx = blockIdx.x * 4 + wv, img = blockIdx.y;
-    if (sidx >= nseeds[img]) return;                       // whole wave exits; no block-level barrier below
-    const unsigned sd = seeds[(long long)img * dv.seed_cap + sidx];
-    const int o = sd >> 28;
-    int l = (sd >> 26) & 3, r = (sd >> 13) & 0x1FFF, c = sd & 0x1FFF;
+    const int img = blockIdx.y, ns = nsurv[img];
+    // waves stride over the survivor list (a grid sized for seed_cap would be millions of empty workgroups)
+    for (int sidx = blockIdx.x * 4 + wv; sidx < ns; sidx += gridDim.x * 4) {
+    const float *sq = surv + ((long long)img * dv.seed_cap + sidx) * SURV_W;
+    const unsigned sd = (unsigned)__float_as_int(sq[0]);
+    const int o = sd >> 28, l = (sd >> 26) & 3, r = (sd >> 13) & 0x1FFF, c = sd & 0x1FFF;
+    const float xi = sq[1], xr = sq[2], xc = sq[3], contr = sq[4];
     const int w = dv.w[o], h = dv.h[o];
     const long long n = (long long)w * h;
-    DogCtx dc = {dog + (long long)img * dv.dstride + dv.doff[o], n, w, h};
-    float xi = 0, xr = 0, xc = 0, contr = 0;
-    int ok = 0;
-    if (lane == 0) ok = sift_adjust(dc, l, r, c, xi, xr, xc, contr) ? 1 : 0;
-    ok = __shfl(ok, 0);
-    if (!ok) return;
-    l = __shfl(l, 0); r = __shfl(r, 0); c = __shfl(c, 0);
-    xi = __shfl(xi, 0); xr = __shfl(xr, 0); xc = __shfl(xc, 0); contr = __shfl(contr, 0);
     const float kx = ((float)c + xc) * (float)(1 << o), ky = ((float)r + xr) * (float)(1 << o);
     const int koct = o + (l << 8) + (__double2int_rn(((double)xi + 0.5) * 255) << 16);
     const float ksize = 1.6f * det_exp2f(((float)l + xi) / S_NOL) * (float)(1 << o) * 2;
@@ -507,18 +526,37 @@ __global__ __launch_bounds__(256) void sift_refine_kernel(const float *__restric
     volatile float (*part)[8] = s_part[wv];
     for (int i = lane; i < S_BINS * 8; i += 64) ((volatile float *)part)[i] = 0.f;
     const int side = 2 * radius + 1, nsamp = side * side;
-    for (int k0 = 0; k0 < nsamp; k0 += 64) {
-        const int k = k0 + lane;
-        bool valid = k < nsamp;
-        int bin = 0; float contrib = 0.f;
-        if (valid) {
-            const int i = k / side - radius, j = k % side - radius;
+    const float inv_side = 1.f / (float)side;
+    constexpr int DU = 4;                                   // batches whose gradient loads fly together
+    for (int k0 = 0; k0 < nsamp; k0 += 64 * DU) {
+        bool vld[DU];
+        int di2[DU];
+        float g0[DU], g1[DU], g2[DU], g3[DU];
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int k = k0 + 64 * u + lane;
+            int qi = (int)((float)k * inv_side);
+            int rem = k - qi * side;
+            if (rem < 0) { --qi; rem += side; } else if (rem >= side) { ++qi; rem -= side; }
+            const int i = qi - radius, j = rem - radius;
             const int y = r + i, x = c + j;
-            valid = !(y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1);
+            di2[u] = i * i + j * j;
+            vld[u] = k < nsamp && !(y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1);
+            g0[u] = g1[u] = g2[u] = g3[u] = 0.f;
+            if (vld[u]) {
+                const float *pc = img_l + (size_t)y * w + x;
+                g0[u] = pc[1]; g1[u] = pc[-1]; g2[u] = pc[-w]; g3[u] = pc[w];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            if (k0 + 64 * u >= nsamp) break;                // wave-uniform
+            const bool valid = vld[u];
+            int bin = 0; float contrib = 0.f;
             if (valid) {
-                const float dx = img_l[(size_t)y * w + x + 1] - img_l[(size_t)y * w + x - 1];
-                const float dy = img_l[(size_t)(y - 1) * w + x] - img_l[(size_t)(y + 1) * w + x];
-                const float wgt = det_expf((float)(i * i + j * j) * expf_scale);
+                const float dx = g0[u] - g1[u];
+                const float dy = g2[u] - g3[u];
+                const float wgt = det_expf((float)di2[u] * expf_scale);
                 const float ori = fast_atan2_deg(dy, dx);
                 const float mag = sqrtf(dx * dx + dy * dy);
                 bin = __float2int_rn((S_BINS / 360.f) * ori);
@@ -526,12 +564,12 @@ __global__ __launch_bounds__(256) void sift_refine_kernel(const float *__restric
                 if (bin < 0) bin += S_BINS;
                 contrib = wgt * mag;
             }
-        }
-        // 8 rounds of 8 lanes: slot (lane & 7) receives its samples in ascending k
+            // 8 rounds of 8 lanes: slot (lane & 7) receives its samples in ascending k
 #pragma unroll
-        for (int rd = 0; rd < 8; ++rd) {
-            if ((lane >> 3) == rd && valid) part[bin][lane & 7] = part[bin][lane & 7] + contrib;
-            __builtin_amdgcn_wave_barrier();
+            for (int rd = 0; rd < 8; ++rd) {
+                if ((lane >> 3) == rd && valid) part[bin][lane & 7] = part[bin][lane & 7] + contrib;
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
     volatile float *th = s_hist[wv] + 2;
@@ -563,6 +601,8 @@ __global__ __launch_bounds__(256) void sift_refine_kernel(const float *__restric
             float *q = raw + ((long long)img * dv.raw_cap + slot) * 6;
             q[0] = kx; q[1] = ky; q[2] = ksize; q[3] = angle; q[4] = kresp; q[5] = __int_as_float(koct);
         } else overflow[img] = 1;
+    }
+    __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -766,20 +806,43 @@ __global__ __launch_bounds__(256) void sift_describe_kernel(const float *__restr
     volatile float *stg = s_stage[wv];
     for (int i = lane; i < 360 * 8; i += 64) ((volatile float *)part)[i] = 0.f;
     const int side = 2 * radius + 1, nsamp = side * side;
-    for (int k0 = 0; k0 < nsamp; k0 += 64) {
-        const int k = k0 + lane;
-        bool valid = k < nsamp;
+    const float inv_side = 1.f / (float)side;
+    // DU batches of 64 samples per trip: the 4*DU gradient loads of a lane are issued before anything
+    // consumes them (the loop was one exposed L2/HBM round trip per 64 samples)
+    constexpr int DU = 4;
+    for (int k0 = 0; k0 < nsamp; k0 += 64 * DU) {
+        bool vld[DU];
+        float crot[DU], rrot[DU], rbn[DU], cbn[DU], g0[DU], g1[DU], g2[DU], g3[DU];
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int k = k0 + 64 * u + lane;
+            // k / side without the integer divider: float estimate, one correction step (k < 2^24)
+            int qi = (int)((float)k * inv_side);
+            int rem = k - qi * side;
+            if (rem < 0) { --qi; rem += side; } else if (rem >= side) { ++qi; rem -= side; }
+            const int i = qi - radius, j = rem - radius;
+            crot[u] = j * cos_t - i * sin_t; rrot[u] = j * sin_t + i * cos_t;
+            rbn[u] = rrot[u] + d / 2 - 0.5f; cbn[u] = crot[u] + d / 2 - 0.5f;
+            const int r = py + i, c = px + j;
+            vld[u] = k < nsamp && rbn[u] > -1 && rbn[u] < d && cbn[u] > -1 && cbn[u] < d && r > 0 && r < h - 1 && c > 0 && c < w - 1;
+            g0[u] = g1[u] = g2[u] = g3[u] = 0.f;
+            if (vld[u]) {
+                const float *pc = img_l + (size_t)r * w + c;
+                g0[u] = pc[1]; g1[u] = pc[-1]; g2[u] = pc[-w]; g3[u] = pc[w];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+        if (k0 + 64 * u >= nsamp) break;                                  // wave-uniform
+        const bool valid = vld[u];
         int idx = 0;
         float v000 = 0, v001 = 0, v010 = 0, v011 = 0, v100 = 0, v101 = 0, v110 = 0, v111 = 0;
         if (valid) {
-            const int i = k / side - radius, j = k % side - radius;
-            const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
-            float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
-            const int r = py + i, c = px + j;
-            valid = rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1;
-            if (valid) {
-                const float dx = img_l[(size_t)r * w + c + 1] - img_l[(size_t)r * w + c - 1];
-                const float dy = img_l[(size_t)(r - 1) * w + c] - img_l[(size_t)(r + 1) * w + c];
+            float rbin = rbn[u], cbin = cbn[u];
+            const float c_rot = crot[u], r_rot = rrot[u];
+            {
+                const float dx = g0[u] - g1[u];
+                const float dy = g2[u] - g3[u];
                 const float wgt = det_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
                 const float oo = fast_atan2_deg(dy, dx);
                 const float mag = sqrtf(dx * dx + dy * dy) * wgt;
@@ -815,6 +878,7 @@ __global__ __launch_bounds__(256) void sift_describe_kernel(const float *__restr
                 if (id >= 0) part[id + qoff][sl] = part[id + qoff][sl] + v;
                 __builtin_amdgcn_wave_barrier();
             }
+        }
         }
     }
     volatile float *hist = s_hist[wv];
@@ -932,6 +996,8 @@ int rpe_sift_create(rpe_handle *h)
     SCHK(hipMalloc(&S->d_nseeds, sizeof(int) * NI));
     SCHK(hipMalloc(&S->d_raw, sizeof(float) * NI * dv.raw_cap * 6));
     SCHK(hipMalloc(&S->d_nraw, sizeof(int) * NI));
+    SCHK(hipMalloc(&S->d_surv, sizeof(float) * NI * dv.seed_cap * SURV_W));
+    SCHK(hipMalloc(&S->d_nsurv, sizeof(int) * NI));
     SCHK(hipMalloc(&S->d_overflow, sizeof(int) * NI));
     SCHK(hipMalloc(&S->d_ncand, sizeof(int) * NI));
     SCHK(hipMalloc(&S->d_k0, sizeof(unsigned long long) * NI * S->raw_pad));
@@ -946,7 +1012,7 @@ void rpe_sift_destroy(rpe_handle *h)
     RpeSiftState *S = h->sift;
     if (!S) return;
     void *p[] = {S->d_gauss, S->d_dog, S->d_tmp, S->d_xtiles, S->d_xmask, S->d_band_cnt, S->d_band_off, S->d_seeds, S->d_nseeds, S->d_raw,
-                 S->d_nraw, S->d_overflow, S->d_ncand, S->d_k0, S->d_k1, S->d_sidx, S->d_fin};
+                 S->d_nraw, S->d_overflow, S->d_ncand, S->d_k0, S->d_k1, S->d_sidx, S->d_fin, S->d_surv, S->d_nsurv};
     for (void *q : p) if (q) hipFree(q);
     delete S;
     h->sift = nullptr;
@@ -1019,8 +1085,11 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
     // 4. refine + orientation -> raw keypoints
     hipMemsetAsync(S->d_nraw, 0, sizeof(int) * n, h->stream);
     hipMemsetAsync(S->d_overflow, 0, sizeof(int) * n, h->stream);
-    hipLaunchKernelGGL(sift_refine_kernel, dim3((dv.seed_cap + 3) / 4, n), dim3(256), 0, h->stream, (const float *)S->d_gauss,
-                       (const float *)S->d_dog, dv, (const unsigned *)S->d_seeds, (const int *)S->d_nseeds, S->d_raw, S->d_nraw, S->d_overflow);
+    hipMemsetAsync(S->d_nsurv, 0, sizeof(int) * n, h->stream);
+    hipLaunchKernelGGL(sift_adjust_kernel, dim3((dv.seed_cap + 255) / 256, n), dim3(256), 0, h->stream, (const float *)S->d_dog, dv,
+                       (const unsigned *)S->d_seeds, (const int *)S->d_nseeds, S->d_surv, S->d_nsurv);
+    hipLaunchKernelGGL(sift_orient_kernel, dim3(2048, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
+                       (const float *)S->d_surv, (const int *)S->d_nsurv, S->d_raw, S->d_nraw, S->d_overflow);
     // 5. sort, dedup, retainBest, compaction
     hipLaunchKernelGGL(sift_prefilter_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_raw, (const int *)S->d_nraw, dv, S->raw_pad,
                        S->d_k0, S->d_k1, S->d_sidx, S->d_ncand, S->d_overflow);
