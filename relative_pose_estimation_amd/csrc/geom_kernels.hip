@@ -684,18 +684,29 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const double2 *__rest
     }
 }
 
-// Sequential replay of OpenCV's update rule (ptsetreg.cpp) over the counts of one chunk:
-// "strictly more inliers wins", niters shrinks through RANSACUpdateNumIters, the loop stops at niters.
-__global__ __launch_bounds__(64) void ransac_update_kernel(RpeRansacState *__restrict__ st, const double *__restrict__ models,
+// Replay of OpenCV's sequential update rule (ptsetreg.cpp) over the counts of one chunk: "strictly
+// more inliers wins", niters shrinks through RANSACUpdateNumIters, the loop stops at niters.
+// RANSACUpdateNumIters(.., niters) == min(niters, R(good)) with R tabulated on the host (0 when the
+// log underflows, unbounded when denom >= 0), so the serial recurrence is a pair of scans: one wave per
+// pair, lane = iteration, 64 iterations per step: exclusive prefix max of the per-iteration best count
+// (who is a record breaker), per-lane replay of its <= 10 models against that prefix, exclusive prefix
+// min of the resulting niters, first lane whose iteration index reaches its niters = the break.
+// Bit-identical to the serial loop (it was 0.25-1.1 ms of single-lane latency per step).
+__device__ __forceinline__ int niters_cap(const double *nit_denom, const int *nit_round, double num, int M, int good, int niters)
+{
+    return update_niters(nit_denom, nit_round, num, M, good, niters);
+}
+
+__global__ __launch_bounds__(256) void ransac_update_kernel(RpeRansacState *__restrict__ st, const double *__restrict__ models,
                                                             const int *__restrict__ nmodels, const int *__restrict__ counts,
                                                             const double *__restrict__ nit_denom, const int *__restrict__ nit_round,
                                                             double nit_num, double *__restrict__ E_out, int *__restrict__ found,
                                                             int chunk, int n_pairs)
 {
-    const int pair = blockIdx.x * 64 + threadIdx.x;
+    const int lane = threadIdx.x & 63, pair = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pair >= n_pairs) return;
     RpeRansacState s = st[pair];
-    if (s.done) return;
+    if (s.done) return;                                   // wave-uniform
     const int M = s.M;
     const long long slot0 = (long long)pair * RPE_RANSAC_MAXCHUNK;
     int best = s.best_count, niters = s.niters, bk = -1, bm = -1;
@@ -707,30 +718,77 @@ __global__ __launch_bounds__(64) void ransac_update_kernel(RpeRansacState *__res
         s.iters_run = 1;
     } else {
         const int kmax = min(chunk, s.niters - s.next_iter);
-        for (int k = 0; k < kmax; ++k) {
-            const int it = s.next_iter + k;
-            if (it >= niters) break;
-            s.iters_run = it + 1;
-            const int nm = nmodels[slot0 + k];
-            for (int m = 0; m < nm; ++m) {
-                const int good = counts[(slot0 + k) * RPE_MAX_MODELS + m];
-                if (good > max(best, 4)) {
-                    best = good; bk = k; bm = m; s.best_iter = it; s.best_model = m;
-                    niters = update_niters(nit_denom, nit_round, nit_num, M, good, niters);
+        bool stopped = false;
+        for (int k0 = 0; k0 < kmax && !stopped; k0 += 64) {
+            const int k = k0 + lane, it = s.next_iter + k;
+            const bool act = k < kmax;
+            const int nm = act ? nmodels[slot0 + k] : 0;
+            int c[RPE_MAX_MODELS];
+            int cmax = 0;
+#pragma unroll
+            for (int m = 0; m < RPE_MAX_MODELS; ++m) {
+                c[m] = (m < nm) ? counts[(slot0 + k) * RPE_MAX_MODELS + m] : 0;
+                if (c[m] > 4) cmax = max(cmax, c[m]);          // a model needs > max(best, 4) inliers to count
+            }
+            // exclusive prefix max over the lanes (iterations), seeded with the incoming best
+            int inc = cmax;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc = max(inc, v); }
+            int pre = __shfl_up(inc, 1);
+            if (lane == 0) pre = 0;
+            pre = max(pre, best);
+            // this lane's models against its prefix: local record breakers shrink niters
+            int run = pre, lmin = 0x7FFFFFFF, wm = -1;
+#pragma unroll
+            for (int m = 0; m < RPE_MAX_MODELS; ++m) {
+                if (m < nm && c[m] > max(run, 4)) {
+                    run = c[m]; wm = m;
+                    lmin = min(lmin, niters_cap(nit_denom, nit_round, nit_num, M, c[m], 0x7FFFFFFF));
                 }
             }
+            // exclusive prefix min of niters
+            int pmin = lmin;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(pmin, o); if (lane >= o) pmin = min(pmin, v); }
+            int nit_before = __shfl_up(pmin, 1);
+            if (lane == 0) nit_before = 0x7FFFFFFF;
+            nit_before = min(nit_before, niters);
+            const unsigned long long brk = __ballot(!act || it >= nit_before);
+            const int stop = brk ? (__ffsll((long long)brk) - 1) : 64;       // lanes [0, stop) are processed
+            if (stop > 0) {
+                // state after the last processed lane
+                const int last = stop - 1;
+                const int nbest = __shfl(run, last);
+                const int nnit = min(niters, __shfl(pmin, last));
+                if (nbest > best) {
+                    // the winner is the first processed lane whose run reached nbest (first occurrence of the max)
+                    const unsigned long long wmask = __ballot(lane < stop && run == nbest && wm >= 0);
+                    const int wl = __ffsll((long long)wmask) - 1;
+                    bk = k0 + wl; bm = __shfl(wm, wl);
+                    s.best_iter = s.next_iter + bk; s.best_model = bm;
+                    best = nbest;
+                }
+                niters = nnit;
+                s.iters_run = s.next_iter + k0 + stop;
+            }
+            if (stop < 64) stopped = true;
         }
         s.next_iter += chunk;
     }
-    if (bk >= 0) {
+    if (bk >= 0 && lane < 9) {
         const double *Eg = models + ((slot0 + bk) * RPE_MAX_MODELS + bm) * 9;
-        for (int e = 0; e < 9; ++e) { s.E[e] = Eg[e]; E_out[pair * 9 + e] = Eg[e]; }
+        const double e = Eg[lane];
+        E_out[pair * 9 + lane] = e;
+        st[pair].E[lane] = e;
     }
-    s.best_count = best; s.niters = niters;
-    s.found = best > 0;
-    s.done = s.next_iter >= niters;
-    found[pair] = s.found;
-    st[pair] = s;
+    if (lane == 0) {
+        RpeRansacState *d = st + pair;
+        d->best_count = best; d->niters = niters; d->best_iter = s.best_iter; d->best_model = s.best_model;
+        d->next_iter = s.next_iter; d->iters_run = s.iters_run;
+        d->found = best > 0;
+        d->done = s.next_iter >= niters;
+        found[pair] = best > 0;
+    }
 }
 
 // ------------------------------------------------------------------- mask
@@ -775,7 +833,7 @@ void rpe_launch_ransac(rpe_handle *h, int B, bool want_mask)
         hipLaunchKernelGGL(ransac_score_kernel, dim3(B, wpp), dim3(256), lds, h->stream,
                            n1, n2, (const RpeRansacState *)h->d_rstate, (const double *)h->d_models, (const int *)h->d_nmodels,
                            (const double *)h->d_K, h->cfg.ransac_threshold, h->d_counts, mm);
-        hipLaunchKernelGGL(ransac_update_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream,
+        hipLaunchKernelGGL(ransac_update_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream,
                            h->d_rstate, (const double *)h->d_models, (const int *)h->d_nmodels, (const int *)h->d_counts,
                            (const double *)h->d_nit_denom, (const int *)h->d_nit_round, h->nit_num, h->d_E, h->d_found, chunk, B);
         done_iters += chunk;
