@@ -140,6 +140,16 @@ int rpe_estimate_stream(rpe_handle *h, const uint8_t *h_frames, int F, const dou
                         double *R, double *t, int32_t *inliers, int32_t *n_matches, int32_t *status);
 int rpe_enqueue_stream_device(rpe_handle *h, const uint8_t *d_frames, int F, const double K[9]);
 
+/* Image ingest, the step before the path (reference src/utils/image_loader.py:23-28:
+ * cv2.imread -> BGR, cv2.cvtColor(BGR2GRAY)): interleaved 3-channel uint8 images -> gray with cv2's
+ * fixed-point weights, gray = (B*3735 + G*19235 + R*9798 + 16384) >> 15, on the handle's stream.
+ * order: RPE_ORDER_BGR (cv2.imread layout) or RPE_ORDER_RGB (PIL layout).  n_pixels = total pixels
+ * of all images (tightly packed).  The *_device form is asynchronous: its output can be handed
+ * straight to rpe_enqueue_batch_device / rpe_enqueue_stream_device. */
+enum { RPE_ORDER_BGR = 0, RPE_ORDER_RGB = 1 };
+int rpe_bgr_to_gray_device(rpe_handle *h, const uint8_t *d_bgr, size_t n_pixels, int order, uint8_t *d_gray);
+int rpe_bgr_to_gray(rpe_handle *h, const uint8_t *h_bgr, size_t n_pixels, int order, uint8_t *h_gray);
+
 /* matched point arrays of the last batch (estimate_with_debug's pts1/pts2,
  * pose_estimator.py:606-607,628-629): pts[B*max_matches*2] f32 */
 int rpe_fetch_matched_points(rpe_handle *h, int B, float *pts1, float *pts2);

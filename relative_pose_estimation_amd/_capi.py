@@ -17,6 +17,7 @@ PAIR_OK, PAIR_NO_DESCRIPTORS, PAIR_INSUFFICIENT_MATCHES, PAIR_NO_ESSENTIAL = 0, 
 FEATURE_ORB, FEATURE_SIFT = 0, 1
 NORM_HAMMING, NORM_L2 = 0, 1
 STAGE_COUNT = 12
+ORDER_BGR, ORDER_RGB = 0, 1
 
 EXPORTS = [
     "rpe_default_config", "rpe_create", "rpe_destroy", "rpe_last_error", "rpe_device_count",
@@ -27,6 +28,7 @@ EXPORTS = [
     "rpe_set_profiling", "rpe_get_stage_ms", "rpe_stage_name",
     "rpe_sift_detect_and_compute", "rpe_sift_debug_gauss", "rpe_match_l2",
     "rpe_estimate_stream", "rpe_enqueue_stream_device",
+    "rpe_bgr_to_gray_device", "rpe_bgr_to_gray",
 ]
 
 
@@ -98,6 +100,8 @@ def load():
     lib.rpe_match_l2.restype = C.c_int
     lib.rpe_estimate_stream.argtypes = [vp, vp, C.c_int, vp, vp, vp, i32p, i32p, i32p]; lib.rpe_estimate_stream.restype = C.c_int
     lib.rpe_enqueue_stream_device.argtypes = [vp, vp, C.c_int, vp]; lib.rpe_enqueue_stream_device.restype = C.c_int
+    lib.rpe_bgr_to_gray_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]; lib.rpe_bgr_to_gray_device.restype = C.c_int
+    lib.rpe_bgr_to_gray.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]; lib.rpe_bgr_to_gray.restype = C.c_int
     _lib = lib
     return lib
 
@@ -161,6 +165,30 @@ class Engine:
 
     def synchronize(self):
         self._chk(self.lib.rpe_synchronize(self.h))
+
+    # ---- image ingest (image_loader.py:27-28: BGR2GRAY)
+    def bgr_to_gray(self, images, order=ORDER_BGR):
+        """(..., H, W, 3) uint8 -> (..., H, W) uint8 gray, cv2's fixed-point weights, computed on the GPU."""
+        a = np.ascontiguousarray(images, np.uint8)
+        assert a.shape[-1] == 3, a.shape
+        out = np.empty(a.shape[:-1], np.uint8)
+        self._chk(self.lib.rpe_bgr_to_gray(self.h, _p(a), out.size, order, _p(out)))
+        return out
+
+    def upload_bgr_as_gray(self, images, order=ORDER_BGR):
+        """Upload interleaved 3-channel frames and convert them in HBM; returns the device pointer of
+        the gray frames (caller frees) -- feeds enqueue_batch_device / enqueue_stream_device."""
+        a = np.ascontiguousarray(images, np.uint8)
+        assert a.shape[-1] == 3, a.shape
+        n = a.size // 3
+        d_bgr = self.upload(a)
+        d_gray = self.device_malloc(n)
+        try:
+            self._chk(self.lib.rpe_bgr_to_gray_device(self.h, d_bgr, n, order, d_gray))
+            self.synchronize()
+        finally:
+            self.device_free(d_bgr)
+        return d_gray
 
     # ---- hot path
     def _outs(self, B):

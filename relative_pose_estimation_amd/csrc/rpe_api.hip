@@ -503,6 +503,68 @@ extern "C" int rpe_estimate_stream(rpe_handle *h, const uint8_t *h_frames, int F
     return rpe_fetch_results(h, F - 1, R, t, inliers, n_matches, status);
 }
 
+// ---------------------------------------------------------------- image ingest
+// cv2.cvtColor(BGR2GRAY) (reference src/utils/image_loader.py:27-28), 8-bit path of OpenCV's color_rgb:
+// (B*3735 + G*19235 + R*9798 + (1 << 14)) >> 15.  HBM-bound streaming kernel: a lane turns 16 pixels
+// (three 16-B loads) into one 16-B store; 4 algorithmic bytes per pixel.
+__global__ __launch_bounds__(256) void bgr_to_gray_kernel(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray, size_t n_pixels,
+                                                          unsigned w0, unsigned w1, unsigned w2)
+{
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;        // group of 16 pixels
+    const size_t p0 = g * 16;
+    if (p0 >= n_pixels) return;
+    if (p0 + 16 <= n_pixels) {
+        const uint4 *src = (const uint4 *)(bgr + p0 * 3);
+        const uint4 a = src[0], b = src[1], c = src[2];
+        const unsigned wd[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+        unsigned out[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = 3 * i;
+            const unsigned c0 = (wd[o >> 2] >> (8 * (o & 3))) & 255u;
+            const unsigned c1 = (wd[(o + 1) >> 2] >> (8 * ((o + 1) & 3))) & 255u;
+            const unsigned c2 = (wd[(o + 2) >> 2] >> (8 * ((o + 2) & 3))) & 255u;
+            out[i >> 2] |= ((c0 * w0 + c1 * w1 + c2 * w2 + 16384u) >> 15) << (8 * (i & 3));
+        }
+        *(uint4 *)(gray + p0) = make_uint4(out[0], out[1], out[2], out[3]);
+    } else {
+        for (size_t p = p0; p < n_pixels; ++p)
+            gray[p] = (uint8_t)((bgr[3 * p] * w0 + bgr[3 * p + 1] * w1 + bgr[3 * p + 2] * w2 + 16384u) >> 15);
+    }
+}
+
+extern "C" int rpe_bgr_to_gray_device(rpe_handle *h, const uint8_t *d_bgr, size_t n_pixels, int order, uint8_t *d_gray)
+{
+    if (!h || !d_bgr || !d_gray || (order != RPE_ORDER_BGR && order != RPE_ORDER_RGB)) return RPE_ERR_INVALID;
+    if (((uintptr_t)d_bgr | (uintptr_t)d_gray) & 15) { h->err = "rpe_bgr_to_gray_device: buffers must be 16-byte aligned"; return RPE_ERR_INVALID; }
+    if (n_pixels == 0) return RPE_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const unsigned wb = 3735u, wg = 19235u, wr = 9798u;
+    const size_t groups = (n_pixels + 15) / 16;
+    hipLaunchKernelGGL(bgr_to_gray_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, h->stream, d_bgr, d_gray, n_pixels,
+                       order == RPE_ORDER_BGR ? wb : wr, wg, order == RPE_ORDER_BGR ? wr : wb);
+    HIPCHK(h, hipGetLastError());
+    return RPE_OK;
+}
+
+extern "C" int rpe_bgr_to_gray(rpe_handle *h, const uint8_t *h_bgr, size_t n_pixels, int order, uint8_t *h_gray)
+{
+    if (!h || !h_bgr || !h_gray) return RPE_ERR_INVALID;
+    if (n_pixels == 0) return RPE_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    void *d_in = nullptr, *d_out = nullptr;
+    HIPCHK(h, hipMalloc(&d_in, n_pixels * 3));
+    if (hipMalloc(&d_out, n_pixels) != hipSuccess) { hipFree(d_in); h->err = "hipMalloc failed"; return RPE_ERR_HIP; }
+    int rc = RPE_OK;
+    if (hipMemcpyAsync(d_in, h_bgr, n_pixels * 3, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = RPE_ERR_HIP;
+    if (!rc) rc = rpe_bgr_to_gray_device(h, (const uint8_t *)d_in, n_pixels, order, (uint8_t *)d_out);
+    if (!rc && hipMemcpyAsync(h_gray, d_out, n_pixels, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = RPE_ERR_HIP;
+    if (hipStreamSynchronize(h->stream) != hipSuccess && !rc) rc = RPE_ERR_HIP;
+    hipFree(d_in); hipFree(d_out);
+    if (rc == RPE_ERR_HIP && h->err.empty()) h->err = "rpe_bgr_to_gray: HIP failure";
+    return rc;
+}
+
 extern "C" int rpe_fetch_results(rpe_handle *h, int B, double *R, double *t, int32_t *inliers, int32_t *n_matches, int32_t *status)
 {
     if (!h || B < 1 || B > h->cfg.max_batch) return RPE_ERR_INVALID;

@@ -11,6 +11,8 @@ Run in the build container only (needs /root/reference; the GPU box never sees i
    evaluation runs (decoded from PNG with PIL + cv2's BGR2GRAY fixed-point formula),
    their ground-truth rows and the reference's own result rows
    (evaluation-runs/*/results/evaluation_results.csv).  Data only; no reference source.
+3. evaluator_rows.npz   -- the first 16 rows of the simulator run's evaluation_results.csv with
+   the ground-truth rows of their frames (data only): known answers for the evaluator columns.
 """
 import csv
 import importlib.util
@@ -72,6 +74,14 @@ def main():
         ref_est=np.array([[float(ref[b][k]) for k in ("est_roll", "est_pitch", "est_yaw")] for _, b in pairs]),
         ref_rot_err=np.array([float(ref[b]["rotation_error"]) for _, b in pairs]),
         convention=np.array("yup"))
+    # 3. evaluator_rows.npz -- the first rows of the reference's own evaluation_results.csv (data) with the
+    # ground-truth rows of their frames: pins the evaluator's angle-error columns and the CSV column order
+    rows = list(csv.DictReader(open(f"{base}/results/evaluation_results.csv")))[:16]
+    cols = list(rows[0].keys())
+    np.savez(f"{OUT}/evaluator_rows.npz",
+             columns=np.array(cols),
+             table=np.array([[float(r[c]) if r[c] != "" else np.nan for c in cols] for r in rows]),   # empty field = NaN row of the run
+             gt=np.array([[int(r["frame"])] + gt[int(r["frame"])] for r in rows]))   # frame x y z roll pitch yaw
     print("wrote", os.listdir(OUT))
 
 

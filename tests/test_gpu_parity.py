@@ -309,3 +309,53 @@ def test_stream_equals_pairwise(capi, oracle, K_vga):
         if r["status"] == 0:
             assert np.array_equal(R[i], r["R"]) and np.array_equal(t[i], r["t"]) and inl[i] == r["inliers"]
     pe.close()
+
+
+# ------------------------------------------------------------------ callers either side of the path
+def test_bgr_to_gray_bit_exact(eng1000, capi):
+    """ingest kernel == cv2's fixed-point BGR2GRAY formula (geometry.bgr_to_gray restates it for the fixtures);
+    sizes that are not a multiple of the 16-pixel vector exercise the tail path"""
+    from relative_pose_estimation_amd import geometry as g
+    rng = np.random.default_rng(11)
+    for shape in [(480, 640, 3), (2, 37, 53, 3), (1, 5, 3)]:
+        rgb = rng.integers(0, 256, shape, dtype=np.uint8)
+        want = g.bgr_to_gray(rgb)
+        assert np.array_equal(eng1000.bgr_to_gray(rgb, order=capi.ORDER_RGB), want)
+        assert np.array_equal(eng1000.bgr_to_gray(np.ascontiguousarray(rgb[..., ::-1]), order=capi.ORDER_BGR), want)
+    sat = np.full((4, 16, 3), 255, np.uint8)
+    assert np.all(eng1000.bgr_to_gray(sat) == 255)
+
+
+def test_batch_processor_sequence(capi, oracle, tmp_path):
+    """BatchProcessor.process_sequence on PNG files + camera_poses.txt (the reference's on-disk formats):
+    R_new = R_prev_GT @ R_rel with R_rel bit-equal to the oracle, Euler columns within the forward bound of the
+    reference's own CSV row, colour and gray ingest identical, a failing pair raises the reference's message."""
+    import os
+    from PIL import Image
+    from relative_pose_estimation_amd import PoseEstimator, BatchProcessor, PoseEvaluator, GroundTruthLoader, geometry as g
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "forward_pairs.npz"))
+    f1, f2 = (int(v) for v in z["frames"][0])
+    for f, im in ((f1, z["img1"][0]), (f2, z["img2"][0])):
+        Image.fromarray(np.repeat(im[..., None], 3, axis=2)).save(tmp_path / f"{f:06d}.png")    # gray as R=G=B: BGR2GRAY is the identity
+    with open(tmp_path / "camera_poses.txt", "w") as fh:
+        fh.write("frame x y z roll pitch yaw\n")
+        for f, row in ((f1, z["gt1"][0]), (f2, z["gt2"][0])):
+            fh.write(f"{f} " + " ".join(repr(float(v)) for v in row) + "\n")
+    gl = GroundTruthLoader(tmp_path / "camera_poses.txt"); gl.load()
+    pe = PoseEstimator(z["K"])
+    bp = BatchProcessor(tmp_path, pe, gl, euler_convention="yup")
+    out = bp.process_sequence([f1, f2])
+    r = oracle.estimate_pose(z["img1"][0], z["img2"][0], z["K"], 4000, 500)
+    g1 = z["gt1"][0]
+    R_new = g.euler_to_rotation(g1[5], g1[4], g1[3], "yup") @ r["R"]
+    assert out["frames"] == [f2] and np.array_equal(out["R"][0], R_new) and np.array_equal(out["t"][0], r["t"])
+    ref_roll, ref_pitch, ref_yaw = z["ref_est"][0]
+    assert abs(out["yaw"][0] - ref_yaw) < 1.5 and abs(out["pitch"][0] - ref_pitch) < 1.5 and abs(out["roll"][0] - ref_roll) < 1.5
+    ev = PoseEvaluator(gl, "yup").evaluate_sequence(out)
+    assert ev["rotation_error"][0] <= z["ref_rot_err"][0] + 0.5 and ev["translation_dir_error"][0] == 0.0
+    gray = bp.process_frames([f1, f2], np.stack([z["img1"][0], z["img2"][0]]))
+    assert np.array_equal(gray["R"][0], out["R"][0])
+    flat = np.full((2, 480, 640), 80, np.uint8)
+    with pytest.raises(RuntimeError, match="Could not compute descriptors"):
+        bp.process_frames([f1, f2], flat)
+    pe.close()
