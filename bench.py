@@ -26,20 +26,60 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 measured
 
 
-def stage_bytes(stage, W, H, pyr_px, nkp, mm):
+def orb_levels(W, H, nlevels=12, scale=1.1):
+    """ORB pyramid level sizes (orb.cpp: cvRound(size / scale^l)); sum(w*h) must equal rpe_orb_pyramid_pixels()."""
+    out = []
+    for l in range(nlevels):
+        s = scale ** l
+        out.append((int(np.rint(W / s)), int(np.rint(H / s))))
+    return out
+
+
+def sift_octaves(W, H):
+    """SIFT octave sizes (sift.dispatch.cpp: base = 2x upsampled image, nOctaves = round(log2(min) - 2) + 1)."""
+    bw, bh = 2 * W, 2 * H
+    noct = min(12, int(np.rint(np.log(min(bw, bh)) / np.log(2.0) - 2)) + 1)
+    out = []
+    for o in range(noct):
+        out.append((bw, bh))
+        bw, bh = bw // 2, bh // 2
+    return out
+
+
+def stage_bytes(stage, W, H, pyr_px, nkp, mm, method="ORB"):
     """ALGORITHMIC (compulsory) HBM bytes of one stage for ONE PAIR (= 2 images),
     DESIGN.md 'Algorithmic bytes'.  pyr_px = pixels of one 12-level pyramid."""
     img = W * H
+    if method == "SIFT":
+        px = sum(w * h for w, h in sift_octaves(W, H))
+        per_image = {
+            "pyramid": img + (6 + 5) * 4 * px,           # read the u8 image, write 6 Gaussian + 5 DoG f32 levels per octave
+            "fast": 5 * 4 * px + 3 * px // 8,            # extrema scan: read every DoG level once, write the 1-bit hit mask
+            "select": 27 * 4 * nkp * 8,                  # adjustLocalExtrema: 3x3x3 DoG block per seed (~8 seeds per kept keypoint)
+            "harris": 4 * 4 * 400 * nkp,                 # orientation: 4 gradient taps x ~400 window samples per keypoint
+            "keypoints": 24 * nkp * 4,
+            "describe": 4 * 4 * 4000 * nkp + 128 * nkp,  # descriptor window gradients + 128-B descriptor
+        }
+        if stage in per_image:
+            return 2 * per_image[stage]
+        if stage == "match":
+            return 2 * nkp * 128 + nkp * 8               # u8 descriptors: (N1+N2)*128 + N1*8
+        if stage in ("nms", "angle", "blur"):
+            return 0
+    lv = orb_levels(W, H)
+    assert sum(w * h for w, h in lv) == pyr_px, "level-size formula disagrees with the library"
+    live = [(w, h) for w, h in lv if w > 62 and h > 62]
     per_image = {
         "pyramid": img + pyr_px,                 # read level 0, write the 12-level pyramid
-        "fast": 2 * pyr_px,                      # read pyramid, write score map
-        "nms": 2 * pyr_px + 12 * 256 * 4,        # read score, write NMS map, histogram
-        "select": pyr_px,                        # linear scan of the NMS map
+        # FAST+NMS run on the border-filtered region only: ring reads reach 4 px past the NMS output [31, w-31)
+        "fast": sum((w - 54) * (h - 54) + (w - 62) * (h - 62) for w, h in live) + 12 * 256 * 4,
+        "nms": 0,                                # fused into fast
+        "select": sum(w * (h - 62) for w, h in live),   # linear scan of the NMS map rows that can hold keypoints
         "harris": 81 * 2 * nkp + 8 * 2 * nkp,    # 9x9 patch per candidate (~2*quota kept) + record
         "keypoints": 16 * 2 * nkp,
-        "angle": 749 * nkp + 4 * nkp,            # radius-15 disc per keypoint
-        "blur": 2 * pyr_px,
-        "describe": 512 * nkp + 32 * nkp,        # 512 point samples + 32-byte descriptor
+        "angle": 45 * 45 * nkp + 4 * nkp + 32 * nkp,   # fused orientation + descriptor: one 45x45 patch per keypoint in, angle + 32-B descriptor out
+        "blur": 0,                               # fused into angle (per-keypoint patch blur)
+        "describe": 0,                           # fused into angle
     }
     if stage in per_image:
         return 2 * per_image[stage]
@@ -52,9 +92,14 @@ def stage_bytes(stage, W, H, pyr_px, nkp, mm):
     raise KeyError(stage)
 
 
-STAGE_KERNEL = {"fast": "fast_nms_kernel", "angle": "orient_describe_kernel", "select": "select_candidates_kernel",
-                "harris": "harris_kernel", "keypoints": "select_keypoints_kernel", "match": "match_hamming_kernel",
-                "pose": "recover_pose_kernel"}
+STAGE_KERNEL = {"pyramid": "pyr_resize_kernel", "fast": "fast_nms_kernel", "angle": "orient_describe_kernel",
+                "select": "select_candidates_kernel", "harris": "harris_kernel", "keypoints": "select_keypoints_kernel",
+                "match": "match_hamming_kernel", "ransac": "ransac_*_kernel (group)", "pose": "recover_pose_kernel"}
+# SIFT reuses the stage slots (csrc/sift_kernels.hip rpe_sift_run)
+SIFT_STAGE_KERNEL = {"pyramid": "sift_upsample + sift_blur_fused<R> x16/octave-set (group)", "fast": "sift_extrema_mask_kernel (+scan, emit)",
+                     "select": "sift_adjust_kernel", "harris": "sift_orient_kernel", "keypoints": "sift_prefilter/sort/finalize (group)",
+                     "describe": "sift_describe_kernel", "match": "match_l2_nearest_kernel (+select)",
+                     "ransac": "ransac_*_kernel (group)", "pose": "recover_pose_kernel"}
 
 
 def pmc_traffic(stage, pairs_per_launch, W, H, nfeatures):
@@ -248,13 +293,11 @@ def main():
 
     if rank == 0:
         dom = max(stage_ms, key=stage_ms.get)
-        if method == "SIFT":
-            dom = "match"          # SIFT extraction is a multi-kernel group; the roofline line prices the L2 matcher
-        dom_bytes = stage_bytes(dom, W, H, pyr_px, args.nfeatures, args.max_matches) * Bl if method == "ORB" else \
-            (2 * args.nfeatures * 128 + args.nfeatures * 8) * Bl
+        names = SIFT_STAGE_KERNEL if method == "SIFT" else STAGE_KERNEL
+        dom_bytes = stage_bytes(dom, W, H, pyr_px, args.nfeatures, args.max_matches, method) * Bl
         achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
         # the matcher is the stage north_star attaches a roofline target to: always report it too
-        m_bytes = stage_bytes("match", W, H, pyr_px, args.nfeatures, args.max_matches) * Bl if method == "ORB" else dom_bytes
+        m_bytes = stage_bytes("match", W, H, pyr_px, args.nfeatures, args.max_matches, method) * Bl
         m_achieved = m_bytes / (stage_ms["match"] * 1e-3) / 1e9
         out = {
             "metric": "image-pairs/s end-to-end (640x480 pairs), median rotation-angle error alongside",
@@ -267,18 +310,18 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8/i32 (ORB, Hamming) + f64 (RANSAC, pose)",
+            "dtype": "u8/i32 (ORB, Hamming) + f64 (RANSAC, pose)" if method == "ORB" else "f32 (SIFT) + u8/i32 (exact L2) + f64 (RANSAC, pose)",
             "data": "synthetic",
             "config": {"workload": (f"{B} {W}x{H} pairs per GPU, ORB({args.nfeatures}kp)+BF-Hamming crossCheck top-{args.max_matches}"
                                     "+5pt-RANSAC(0.999,1px)+recoverPose (BASELINE configs[1])" +
                                     (f"; consecutive-frame stream of {B + 1} frames, features once per frame (configs[4] stand-in)" if args.stream else "")) if method == "ORB" else
                                    (f"{B} {W}x{H} pairs per GPU in sub-batches of {sub}, SIFT(cap {args.nfeatures})+BF-L2 crossCheck "
-                                    f"top-{args.max_matches}+5pt-RANSAC+recoverPose (BASELINE configs[2] shape, reduced pair count)"),
+                                    f"top-{args.max_matches}+5pt-RANSAC+recoverPose (BASELINE configs[2]" + ("" if B >= 4096 else f" shape, {B} of its 4096 pairs") + ")"),
                        "pairs_per_gpu": B, "global_pairs": world * B, "streams_per_gpu": S, "pairs_per_launch": Bl, "sharding": f"pairs x{world}, RCCL all-gather of 128-B pose records"},
             "median_rotation_error_deg": float(np.median(errs)) if len(errs) else None,
             "pairs_ok": int(ok.sum()),
             "stage_ms_per_launch": {k: round(v, 4) for k, v in stage_ms.items()},
-            "roofline": {"kernel": STAGE_KERNEL.get(dom, dom), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": names.get(dom, dom), "stage": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, Bl, W, H, args.nfeatures),
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": stage_ms[dom],
                          "matcher": {"achieved": m_achieved, "frac": m_achieved / HBM_PEAK_GBS,

@@ -370,7 +370,6 @@ extern "C" int rpe_synchronize(rpe_handle *h)
 }
 
 // ------------------------------------------------------------- orchestration
-#define MARK(h, stage) do { if ((h)->profiling) hipEventRecord((h)->ev[stage], (h)->stream); } while (0)
 
 // copies level 0 of every image into the pyramid buffer (device to device)
 static int load_level0(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, int nb)
@@ -432,9 +431,8 @@ extern "C" int rpe_enqueue_batch_device(rpe_handle *h, const uint8_t *d_imgs1, c
     int rc = set_K(h, K);
     if (rc) return rc;
     if (h->cfg.feature_method == RPE_FEATURE_SIFT) {
-        MARK(h, RPE_STAGE_PYRAMID);
-        if ((rc = rpe_sift_run(h, d_imgs1, d_imgs2, B, B)) != RPE_OK) return rc;
-        for (int s = RPE_STAGE_FAST; s <= RPE_STAGE_MATCH; ++s) MARK(h, s);
+        if ((rc = rpe_sift_run(h, d_imgs1, d_imgs2, B, B)) != RPE_OK) return rc;       // records PYRAMID .. DESCRIBE
+        MARK(h, RPE_STAGE_MATCH);
         rpe_launch_match_l2(h, B);
     } else {
         if ((rc = run_orb(h, d_imgs1, d_imgs2, B, B)) != RPE_OK) return rc;
@@ -461,9 +459,8 @@ extern "C" int rpe_enqueue_stream_device(rpe_handle *h, const uint8_t *d_frames,
     if (rc) return rc;
     h->img2_base = 1;
     if (h->cfg.feature_method == RPE_FEATURE_SIFT) {
-        MARK(h, RPE_STAGE_PYRAMID);
-        if ((rc = rpe_sift_run(h, d_frames, d_frames, F, 0)) != RPE_OK) return rc;
-        for (int s = RPE_STAGE_FAST; s <= RPE_STAGE_MATCH; ++s) MARK(h, s);
+        if ((rc = rpe_sift_run(h, d_frames, d_frames, F, 0)) != RPE_OK) return rc;     // records PYRAMID .. DESCRIBE
+        MARK(h, RPE_STAGE_MATCH);
         rpe_launch_match_l2(h, F - 1);
     } else {
         if ((rc = run_orb(h, d_frames, d_frames, F, 0)) != RPE_OK) return rc;

@@ -131,3 +131,6 @@ int rpe_sift_fetch_gauss(rpe_handle *h, int index, float *out);
 long long rpe_sift_gauss_floats(rpe_handle *h);
 void rpe_launch_ransac(rpe_handle *h, int B, bool want_mask);
 void rpe_launch_pose(rpe_handle *h, int B, bool set_status);
+
+// per-stage hipEvents on the handle's stream (rpe_set_profiling / rpe_get_stage_ms)
+#define MARK(h, stage) do { if ((h)->profiling) hipEventRecord((h)->ev[stage], (h)->stream); } while (0)

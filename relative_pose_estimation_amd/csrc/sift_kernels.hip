@@ -1053,6 +1053,10 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
     const SiftDev &dv = S->dv;
     const int W = h->cfg.width, H = h->cfg.height, bw = 2 * W, bh = 2 * H;
     const size_t img = (size_t)W * H;
+    // stage events (rpe_get_stage_ms slots reused for SIFT): PYRAMID = upsample + Gaussian pyramid + DoG, FAST = extrema
+    // scan, SELECT = adjustLocalExtrema, HARRIS = orientation histograms, KEYPOINTS = prefilter + sort + retainBest,
+    // DESCRIBE = descriptors; NMS / ANGLE / BLUR are empty
+    MARK(h, RPE_STAGE_PYRAMID);
     // 1. upsample + initial blur -> gaussian[0][0]
     for (int part = 0; part < 2; ++part) {
         const uint8_t *src = part ? d_b : d_a; const int cnt = part ? nb : na, first = part ? na : 0;
@@ -1075,6 +1079,7 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
                       S->d_dog + dv.doff[o] + (i - 1) * pn, dv.dstride, w, hh, i, n);
     }
     // 3. seeds (count, scan, emit)
+    MARK(h, RPE_STAGE_FAST);
     hipMemsetAsync(S->d_band_cnt, 0, sizeof(int) * (size_t)n * dv.nbands, h->stream);
     if (S->n_xtiles)
         hipLaunchKernelGGL(sift_extrema_mask_kernel, dim3(S->n_xtiles, n), dim3(256), 0, h->stream, (const float *)S->d_dog, dv,
@@ -1085,12 +1090,15 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
     // 4. refine + orientation -> raw keypoints
     hipMemsetAsync(S->d_nraw, 0, sizeof(int) * n, h->stream);
     hipMemsetAsync(S->d_overflow, 0, sizeof(int) * n, h->stream);
+    MARK(h, RPE_STAGE_NMS); MARK(h, RPE_STAGE_SELECT);
     hipMemsetAsync(S->d_nsurv, 0, sizeof(int) * n, h->stream);
     hipLaunchKernelGGL(sift_adjust_kernel, dim3((dv.seed_cap + 255) / 256, n), dim3(256), 0, h->stream, (const float *)S->d_dog, dv,
                        (const unsigned *)S->d_seeds, (const int *)S->d_nseeds, S->d_surv, S->d_nsurv);
+    MARK(h, RPE_STAGE_HARRIS);
     hipLaunchKernelGGL(sift_orient_kernel, dim3(2048, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
                        (const float *)S->d_surv, (const int *)S->d_nsurv, S->d_raw, S->d_nraw, S->d_overflow);
     // 5. sort, dedup, retainBest, compaction
+    MARK(h, RPE_STAGE_KEYPOINTS);
     hipLaunchKernelGGL(sift_prefilter_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_raw, (const int *)S->d_nraw, dv, S->raw_pad,
                        S->d_k0, S->d_k1, S->d_sidx, S->d_ncand, S->d_overflow);
     hipLaunchKernelGGL(sift_sort_kernel, dim3(n), dim3(1024), 0, h->stream, (const int *)S->d_ncand, S->raw_pad, S->d_k0, S->d_k1, S->d_sidx);
@@ -1098,6 +1106,7 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
                        (const unsigned long long *)S->d_k0, (const unsigned long long *)S->d_k1, (const unsigned *)S->d_sidx,
                        S->d_fin, h->d_kp_pt, h->d_kp_count);
     // 6. descriptors
+    MARK(h, RPE_STAGE_ANGLE); MARK(h, RPE_STAGE_BLUR); MARK(h, RPE_STAGE_DESCRIBE);
     hipLaunchKernelGGL(sift_describe_kernel, dim3((dv.kcap + 3) / 4, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
                        (const float *)S->d_fin, (const int *)h->d_kp_count, h->d_desc);
     SCHK(hipGetLastError());
