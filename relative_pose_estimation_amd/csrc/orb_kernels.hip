@@ -102,10 +102,12 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
         for (int j = 0; j < 4; ++j) {
             unsigned v = 0;
             if (x4 + j < D.w) {
-                int o0 = o[j], o1 = min(o0 + 1, S.w - 1), a0c = 256 - a1[j];
-                unsigned h0 = (unsigned)(a0c * r0[o0] + a1[j] * r0[o1]);
-                unsigned h1 = (unsigned)(a0c * r1[o0] + a1[j] * r1[o1]);
-                v = ((unsigned)b0 * h0 + (unsigned)b1[rr] * h1 + 32768u) >> 16;
+                // all factors fit 24 bits: v_mad_u32_u24 (full rate) instead of the quarter-rate 32-bit multiply
+                const int o0 = o[j], o1 = min(o0 + 1, S.w - 1);
+                const unsigned a0c = 256u - (unsigned)a1[j], a1u = (unsigned)a1[j];
+                const unsigned h0 = __umul24(a0c, r0[o0]) + __umul24(a1u, r0[o1]);
+                const unsigned h1 = __umul24(a0c, r1[o0]) + __umul24(a1u, r1[o1]);
+                v = (__umul24((unsigned)b0, h0) + __umul24((unsigned)b1[rr], h1) + 32768u) >> 16;
             }
             out |= v << (8 * j);
         }
@@ -417,6 +419,7 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const uint8_t *_
         int ex = block_excl_scan(cnt, s_wave, total);
         if (cnt) {
             int o = base + ex;
+            const int y0p = pos / L.pitch, x0p = pos - y0p * L.pitch;     // one division per lane, not one per byte
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const unsigned wds[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
@@ -425,7 +428,12 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const uint8_t *_
                 for (int k = 0; k < 16; ++k) {
                     int b = (int)((wds[k >> 2] >> (8 * (k & 3))) & 255);
                     if (b >= tau) {
-                        if (o < ccap) { int p = pos + 16 * q + k; int y = p / L.pitch; int x = p - y * L.pitch; out[o] = ((unsigned)(y + row0) << 16) | (unsigned)x; }
+                        if (o < ccap) {
+                            int x = x0p + 16 * q + k, y = y0p;            // 64 bytes cross at most two row ends (pitch >= 48)
+                            if (x >= L.pitch) { x -= L.pitch; ++y; }
+                            if (x >= L.pitch) { x -= L.pitch; ++y; }
+                            out[o] = ((unsigned)(y + row0) << 16) | (unsigned)x;
+                        }
                         ++o;
                     }
                 }
