@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--max-matches", type=int, default=500)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--cpu-sample", type=int, default=128)
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="pairs of the batch the CPU oracle is timed on (about 10 s on a 16-core share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gen-workers", type=int, default=0)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3],
@@ -171,8 +171,8 @@ def main():
             args.nfeatures = 2048
         if args.batch == 1024:
             args.batch = 128
-        if args.cpu_sample == 128:
-            args.cpu_sample = 16
+        if args.cpu_sample == 1024:
+            args.cpu_sample = 48
     W, H, B = args.width, args.height, args.batch
     sub = args.sub_batch or (32 if method == "SIFT" else B)
     K = geometry.default_camera_matrix(W, H)
