@@ -43,56 +43,59 @@ __device__ __forceinline__ int xcd_tile(int b, int n)
 }
 
 // ---------------------------------------------------------------- pyramid
-// Workgroup = 64x64 destination tile of level l.  The source footprint in level l-1
-// (<= 74 rows x 80 bytes, bounds derived arithmetically so the loads do not depend on
-// the coefficient tables) is staged in LDS with aligned dword loads -- ~5.9 KB in
-// flight per workgroup; one lane = 4 rows x 4 destination pixels.
+// Workgroup = 128x64 destination tile of level l.  The source footprint in level l-1
+// (<= 74 rows x 152 bytes, bounds derived arithmetically so the loads do not depend on
+// the coefficient tables; checked on the host) is staged in LDS with aligned dword loads, all of
+// them in flight before the first LDS store -- ~11 KB per workgroup: the kernel is bound by the
+// HBM round trip of that window, so a wider tile (half as many workgroups, twice the bytes in
+// flight each) is what shortens it; one lane = 8 rows x 4 destination pixels.
+#define PYR_TW 128
 #define PYR_ROWS 74
-#define PYR_DW 20
+#define PYR_DW 44                    // 176 B per window row = 11 x 16-B loads (origin aligned down to 16 B)
 __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDeviceLayout lay, const int *__restrict__ coef, int l)
 {
-    __shared__ unsigned s_src[PYR_ROWS * PYR_DW];
+    __shared__ __attribute__((aligned(16))) unsigned s_src[PYR_ROWS * PYR_DW];
     const RpeLevel &S = lay.lv[l - 1];
     const RpeLevel &D = lay.lv[l];
     const int tid = threadIdx.x;
-    const int tcols = (D.pitch + 63) >> 6, trows = (D.h + 63) >> 6;
+    const int tcols = (D.pitch + PYR_TW - 1) / PYR_TW, trows = (D.h + 63) >> 6;
     const int ti = xcd_tile(blockIdx.x, tcols * trows);
     if (ti >= tcols * trows) return;
-    const int x0 = (ti % tcols) * 64, y0 = (ti / tcols) * 64;
+    const int x0 = (ti % tcols) * PYR_TW, y0 = (ti / tcols) * 64;
     uint8_t *base = pyr + (long long)blockIdx.y * lay.stride;
     const uint8_t *src = base + S.off;
     const int *xo = coef + D.coef_off, *xa = xo + D.w, *yo = xa + D.w, *ya = yo + D.h;
     // conservative footprint: floor(scale*x0) <= xo[x0] (scale >= 1), checked on the host
-    const int a0 = ((int)(((long long)x0 * S.w) / D.w)) & ~3;
+    const int a0 = ((int)(((long long)x0 * S.w) / D.w)) & ~15;
     const int sy0 = (int)(((long long)y0 * S.h) / D.h);
-    const int tx = tid & 15, tyb = tid >> 4;
+    const int tx = tid & 31, tyb = tid >> 5;
     const int x4 = x0 + 4 * tx;
+    {   // all window loads (16 B per lane) in flight before the first LDS store (one HBM round trip per tile)
+        constexpr int NQ = PYR_DW / 4, NLD = (PYR_ROWS * NQ + 255) / 256;
+        uint4 stage[NLD];
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int i = min(tid + 256 * q, PYR_ROWS * NQ - 1);
+            const int r = i / NQ, c = i - r * NQ;
+            const int y = min(sy0 + r, S.h - 1);
+            const int x = min(a0 + 16 * c, S.pitch - 16);       // pitch is a multiple of 16; clamped columns are never read
+            stage[q] = *(const uint4 *)(src + (long long)y * S.pitch + x);
+        }
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) { const int i = tid + 256 * q; if (i < PYR_ROWS * NQ) ((uint4 *)s_src)[i] = stage[q]; }
+    }
     int o[4], a1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { int x = min(x4 + j, D.w - 1); o[j] = xo[x]; a1[j] = xa[x]; }
-    int oy[4], b1[4];
+    int oy[8], b1[8];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) { int y = min(y0 + tyb + 16 * rr, D.h - 1); oy[rr] = yo[y]; b1[rr] = ya[y]; }
-    {   // all window loads in flight before the first LDS store (one HBM round trip, not six)
-        constexpr int NLD = (PYR_ROWS * PYR_DW + 255) / 256;
-        unsigned stage[NLD];
-#pragma unroll
-        for (int q = 0; q < NLD; ++q) {
-            const int i = min(tid + 256 * q, PYR_ROWS * PYR_DW - 1);
-            const int r = i / PYR_DW, c = i - r * PYR_DW;
-            const int y = min(sy0 + r, S.h - 1);
-            const int x = min(a0 + 4 * c, S.pitch - 4);
-            stage[q] = *(const unsigned *)(src + (long long)y * S.pitch + x);
-        }
-#pragma unroll
-        for (int q = 0; q < NLD; ++q) { const int i = tid + 256 * q; if (i < PYR_ROWS * PYR_DW) s_src[i] = stage[q]; }
-    }
+    for (int rr = 0; rr < 8; ++rr) { int y = min(y0 + tyb + 8 * rr, D.h - 1); oy[rr] = yo[y]; b1[rr] = ya[y]; }
     __syncthreads();
     if (x4 >= D.pitch) return;
     const uint8_t *sb = (const uint8_t *)s_src;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int y = y0 + tyb + 16 * rr;
+    for (int rr = 0; rr < 8; ++rr) {
+        const int y = y0 + tyb + 8 * rr;
         if (y >= D.h) break;
         const int b0 = 256 - b1[rr];
         const uint8_t *r0 = sb + (oy[rr] - sy0) * (PYR_DW * 4) - a0;
@@ -119,7 +122,7 @@ void rpe_launch_pyramid(rpe_handle *h, int n_img)
 {
     for (int l = 1; l < RPE_NLEVELS; ++l) {
         const RpeLevel &D = h->lay.lv[l];
-        const int nt = ((D.pitch + 63) / 64) * ((D.h + 63) / 64);
+        const int nt = ((D.pitch + PYR_TW - 1) / PYR_TW) * ((D.h + 63) / 64);
         hipLaunchKernelGGL(pyr_resize_kernel, dim3((nt + 7) / 8 * 8, n_img), dim3(256), 0, h->stream, h->d_pyr, h->lay, h->d_coef, l);
     }
 }

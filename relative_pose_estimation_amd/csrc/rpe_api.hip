@@ -151,15 +151,15 @@ static int build_tables(rpe_handle *h)
         lin_coeffs(S.w, D.w, xo, xa);
         lin_coeffs(S.h, D.h, yo, ya);
     }
-    // the resize kernel stages a fixed 74-row x 80-byte source footprint per 64x64 tile,
+    // the resize kernel stages a fixed 74-row x 176-byte source footprint per 128x64 tile (origin 16-B aligned),
     // anchored at floor(scale * tile origin); verify the tables fit it for every tile
     for (int l = 1; l < RPE_NLEVELS; ++l) {
         const RpeLevel &S = L.lv[l - 1], &D = L.lv[l];
         const int *xo = coef.data() + D.coef_off, *yo = xo + 2 * D.w;
-        for (int x0 = 0; x0 < D.w; x0 += 64) {
-            int a0 = ((int)(((long long)x0 * S.w) / D.w)) & ~3, xl = x0 + 63 < D.w ? x0 + 63 : D.w - 1;
+        for (int x0 = 0; x0 < D.w; x0 += 128) {
+            int a0 = ((int)(((long long)x0 * S.w) / D.w)) & ~15, xl = x0 + 127 < D.w ? x0 + 127 : D.w - 1;
             int hi = xo[xl] + 1 < S.w ? xo[xl] + 1 : S.w - 1;
-            if (xo[x0] < a0 || hi - a0 >= 80) { h->err = "pyramid footprint bound violated (x)"; return RPE_ERR_INVALID; }
+            if (xo[x0] < a0 || hi - a0 >= 176) { h->err = "pyramid footprint bound violated (x)"; return RPE_ERR_INVALID; }
         }
         for (int y0 = 0; y0 < D.h; y0 += 64) {
             int s0 = (int)(((long long)y0 * S.h) / D.h), yl = y0 + 63 < D.h ? y0 + 63 : D.h - 1;
