@@ -150,6 +150,13 @@ enum { RPE_ORDER_BGR = 0, RPE_ORDER_RGB = 1 };
 int rpe_bgr_to_gray_device(rpe_handle *h, const uint8_t *d_bgr, size_t n_pixels, int order, uint8_t *d_gray);
 int rpe_bgr_to_gray(rpe_handle *h, const uint8_t *h_bgr, size_t n_pixels, int order, uint8_t *h_gray);
 
+/* VP-refinement post-step (pose_estimator.py:160-175 _detect_lsd_lines): line segments of one gray image,
+ * cv2.createLineSegmentDetector(LSD_REFINE_STD).detect(gray) restated (csrc/lsd_host.cpp).  Host code:
+ * the reference runs this step on the CPU after the pose, and so does this library; it needs no handle.
+ * h_lines[capacity*4] receives (x1, y1, x2, y2) per segment; *n_lines is the number found (may exceed
+ * capacity: only the first `capacity` are stored). */
+int rpe_lsd_detect(const uint8_t *h_gray, int width, int height, float *h_lines, int capacity, int32_t *n_lines);
+
 /* matched point arrays of the last batch (estimate_with_debug's pts1/pts2,
  * pose_estimator.py:606-607,628-629): pts[B*max_matches*2] f32 */
 int rpe_fetch_matched_points(rpe_handle *h, int B, float *pts1, float *pts2);

@@ -28,7 +28,7 @@ EXPORTS = [
     "rpe_set_profiling", "rpe_get_stage_ms", "rpe_stage_name",
     "rpe_sift_detect_and_compute", "rpe_sift_debug_gauss", "rpe_match_l2",
     "rpe_estimate_stream", "rpe_enqueue_stream_device",
-    "rpe_bgr_to_gray_device", "rpe_bgr_to_gray",
+    "rpe_bgr_to_gray_device", "rpe_bgr_to_gray", "rpe_lsd_detect",
 ]
 
 
@@ -102,12 +102,26 @@ def load():
     lib.rpe_enqueue_stream_device.argtypes = [vp, vp, C.c_int, vp]; lib.rpe_enqueue_stream_device.restype = C.c_int
     lib.rpe_bgr_to_gray_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]; lib.rpe_bgr_to_gray_device.restype = C.c_int
     lib.rpe_bgr_to_gray.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]; lib.rpe_bgr_to_gray.restype = C.c_int
+    lib.rpe_lsd_detect.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, i32p]; lib.rpe_lsd_detect.restype = C.c_int
     _lib = lib
     return lib
 
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def lsd_detect(gray, capacity=8192):
+    """cv2.createLineSegmentDetector(LSD_REFINE_STD).detect(gray)[0] restated: (N, 4) float64 segments
+    (pose_estimator.py:160-175).  Host code inside librpe_amd.so; needs no GPU handle."""
+    g = np.ascontiguousarray(gray, np.uint8)
+    assert g.ndim == 2
+    out = np.zeros((capacity, 4), np.float32)
+    n = np.zeros(1, np.int32)
+    rc = load().rpe_lsd_detect(_p(g), g.shape[1], g.shape[0], _p(out), capacity, _p(n))
+    if rc != 0:
+        raise RpeError(f"rpe_lsd_detect failed ({rc})")
+    return out[:min(int(n[0]), capacity)].astype(np.float64)
 
 
 class Engine:

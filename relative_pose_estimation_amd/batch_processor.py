@@ -43,10 +43,14 @@ class BatchProcessor:
         if F != len(frame_indices):
             raise ValueError("one frame per frame index expected")
         eng = est._engine(H, W, F - 1)
-        if frames.ndim == 4:                                   # colour: gray conversion in HBM, no host round trip
+        want_vp = bool(getattr(est, "use_vp_refinement", False))
+        gray = None
+        if frames.ndim == 4 and not want_vp:                   # colour: gray conversion in HBM, no host round trip
             d_gray = eng.upload_bgr_as_gray(frames, order=order)
         else:
-            d_gray = eng.upload(np.ascontiguousarray(frames, np.uint8))
+            # the VP post-step (host code, as in the reference) needs the gray frames on the host as well
+            gray = eng.bgr_to_gray(frames, order=order) if frames.ndim == 4 else np.ascontiguousarray(frames, np.uint8)
+            d_gray = eng.upload(gray)
         try:
             eng.enqueue_stream_device(d_gray, F, est.K)
             R_rel, t_rel, inl, nm, st = eng.fetch_results(F - 1)
@@ -57,7 +61,10 @@ class BatchProcessor:
             est._raise_for(int(st[i]), int(nm[i]))
             gt = self.gt_loader.get_pose(frame_indices[i])
             R_prev_world = euler_to_rotation(gt["yaw"], gt["pitch"], gt["roll"], convention=self.euler_convention)
-            R_new_world = R_prev_world @ R_rel[i]               # camera1 -> camera2 composed on the right (:97)
+            R_i = R_rel[i]
+            if want_vp:                                        # estimate(img1, img2, R_prev=R_prev_world) (:92)
+                R_i, _, _ = est._vp_refine(R_i, R_prev_world, gray[i], gray[i + 1])
+            R_new_world = R_prev_world @ R_i                    # camera1 -> camera2 composed on the right (:97)
             yaw, pitch, roll = rotation_to_euler(R_new_world, convention=self.euler_convention)
             out["frames"].append(frame_indices[i + 1])
             out["roll"].append(roll); out["pitch"].append(pitch); out["yaw"].append(yaw)

@@ -6,14 +6,14 @@ estimate_with_debug(...) -> dict with the reference's keys (:571-688, dict
 :624-633), same exception types and messages (:96, :129, :508-509, :514-515,
 :529-530).  Added: estimate_batch() for many pairs per call.
 
-Scope: the feature -> match -> essential -> pose path (ORB + Hamming, SIFT + L2).  VP refinement
-(:160-481, :536-567) is outside the accelerated path: the
-kwargs are accepted and stored; requesting it has no effect on R here and
-'vp_used' is always False.
+Scope: the feature -> match -> essential -> pose path (ORB + Hamming, SIFT + L2) on the GPU.  VP refinement
+(:160-481, :536-567) is the reference's CPU post-step on R; it is applied exactly where the
+reference applies it -- `use_vp_refinement` set and `R_prev` given -- by vp_refinement.py on top of the
+library's LSD restatement (host code, as in the reference).
 """
 import numpy as np
 
-from . import _capi
+from . import _capi, vp_refinement
 
 
 class PoseEstimator:
@@ -119,12 +119,22 @@ class PoseEstimator:
         self._last_n_matches = nm
         return R, t, inl, st
 
+    def _vp_refine(self, R_rel, R_prev, img1, img2):
+        """pose_estimator.py:536-567: (R_rel', vp_used, vp_debug)"""
+        return vp_refinement.refine_relative_rotation(
+            R_rel, R_prev, img1, img2, self.K, max_lines=self.vp_max_lines, max_pairs=self.vp_max_pairs,
+            acc_min=self.vp_acc_min, vp2_min=self.vp_vp2_min, iters=self.vp_iters, lm_lambda=self.vp_lm_lambda,
+            cost_improve_eps=self.vp_cost_improve_eps)
+
     def estimate(self, img1, img2, R_prev=None):
         img1 = self._gray(img1); img2 = self._gray(img2)
         eng = self._engine(img1.shape[0], img1.shape[1], 1)
         R, t, inl, nm, st = eng.estimate_batch(img1[None], img2[None], self.K)
         self._raise_for(int(st[0]), int(nm[0]))
-        return R[0], t[0]
+        R_rel = R[0]
+        if self.use_vp_refinement and R_prev is not None:
+            R_rel, _, _ = self._vp_refine(R_rel, R_prev, img1, img2)
+        return R_rel, t[0]
 
     def estimate_with_debug(self, img1, img2, R_prev=None):
         img1 = self._gray(img1); img2 = self._gray(img2)
@@ -133,7 +143,7 @@ class PoseEstimator:
         self._raise_for(int(st[0]), int(nm[0]))
         p1, p2 = eng.fetch_matched_points(1)
         n = int(nm[0])
-        return {
+        info = {
             'R': R[0],
             't': t[0],
             'num_matches': n,
@@ -143,6 +153,13 @@ class PoseEstimator:
             'vp_used': False,
             'vp_debug': {},
         }
+        if self.use_vp_refinement and R_prev is not None:
+            R_rel, used, dbg = self._vp_refine(R[0], R_prev, img1, img2)
+            info['vp_debug'] = dbg
+            if used:
+                info['R'] = R_rel
+                info['vp_used'] = True
+        return info
 
     def close(self):
         for e in self._engines.values():

@@ -359,3 +359,35 @@ def test_batch_processor_sequence(capi, oracle, tmp_path):
     with pytest.raises(RuntimeError, match="Could not compute descriptors"):
         bp.process_frames([f1, f2], flat)
     pe.close()
+
+
+def test_vp_refinement_call_path(capi, oracle):
+    """use_vp_refinement=True + R_prev: the GPU pose goes through the VP post-step exactly where the reference
+    applies it (pose_estimator.py:536); the debug dict has the reference's structure; when the gates fail or the
+    optimiser's result is rejected, R is the unrefined GPU result bit for bit."""
+    import os
+    from relative_pose_estimation_amd import PoseEstimator, geometry as g
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "forward_pairs.npz"))
+    g1 = z["gt1"][0]
+    R_prev = g.euler_to_rotation(g1[5], g1[4], g1[3], "yup")
+    plain = PoseEstimator(z["K"])
+    R0, t0 = plain.estimate(z["img1"][0], z["img2"][0])
+    plain.close()
+    pe = PoseEstimator(z["K"], use_vp_refinement=True)
+    d = pe.estimate_with_debug(z["img1"][0], z["img2"][0], R_prev=R_prev)
+    vd = d["vp_debug"]
+    assert set(vd) >= {"prev_frame", "new_frame", "vp_extracted", "reliability"} and vd["prev_frame"]["num_lines"] > 50
+    assert set(vd["reliability"]) == {"prev_reliable", "new_reliable"}
+    if not d["vp_used"]:
+        assert np.array_equal(d["R"], R0)
+    R1, t1 = pe.estimate(z["img1"][0], z["img2"][0], R_prev=R_prev)
+    assert np.array_equal(R1, d["R"]) and np.array_equal(t1, t0)
+    R2, _ = pe.estimate(z["img1"][0], z["img2"][0])                       # no R_prev: no VP step
+    assert np.array_equal(R2, R0)
+    # open gates: the optimiser runs, and its (reference-signed) step is accepted only if the cost drops
+    pe2 = PoseEstimator(z["K"], use_vp_refinement=True, vp_acc_min=1.0, vp_vp2_min=1.0)
+    d2 = pe2.estimate_with_debug(z["img1"][0], z["img2"][0], R_prev=R_prev)
+    opt = d2["vp_debug"]["optimization"]
+    assert d2["vp_used"] == opt["cost_improved"]
+    assert np.allclose(d2["R"] @ d2["R"].T, np.eye(3), atol=1e-9)
+    pe.close(); pe2.close()
