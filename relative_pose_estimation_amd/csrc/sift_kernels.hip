@@ -129,29 +129,33 @@ __global__ __launch_bounds__(256) void sift_blur_col_kernel(const float *__restr
 // register window of 8+2R values; tap order and accumulation order are the oracle's
 // (acc = 0; acc += k[i]*v[i], i ascending), so the f32 results are bit-identical.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int R>
+template <int R, int TH>
 __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__restrict__ src, long long sstride, float *__restrict__ dst,
                                                                long long dstride, float *__restrict__ dog, long long dogstride,
                                                                int w, int h, int kid, int tcols, int ntiles)
 {
-    constexpr int WIN = 64 + 2 * R, SP = WIN + 1, KS = 2 * R + 1;
-    __shared__ float s_src[WIN * SP];
-    __shared__ float s_tmp[WIN * 64];
+    // TH = tile height (64 or 32): the LDS footprint (WINH x (SP + 64) floats) decides how many workgroups a CU holds;
+    // at R >= 8 a 64-row tile leaves 2 per CU and the kernel waits on its own window loads, a 32-row tile fits 4
+    constexpr int WIN = 64 + 2 * R, WINH = TH + 2 * R, SP = WIN + 1, KS = 2 * R + 1;
+    __shared__ float s_src[WINH * SP];
+    __shared__ float s_tmp[WINH * 64];
     const int tid = threadIdx.x;
-    const int ti = blockIdx.x;
+    // XCD-aware order: each XCD walks a contiguous raster run of tiles, so neighbouring windows (2R-wide shared halos)
+    // meet in one L2 instead of being fetched by two
+    const int ti = ((blockIdx.x & 7) * ((ntiles + 7) >> 3)) + (blockIdx.x >> 3);
     if (ti >= ntiles) return;
-    const int x0 = (ti % tcols) * 64, y0 = (ti / tcols) * 64;
+    const int x0 = (ti % tcols) * 64, y0 = (ti / tcols) * TH;
     const float *s = src + (long long)blockIdx.y * sstride;
     if (w > R && h > R) {
         // window load, all requests in flight before the first LDS store: with one reflection being
         // enough (n > R; coordinates past n-1+R only feed outputs outside the image and are clamped)
         // the addresses are branch-free, so the loads are issued back to back instead of one
         // HBM round trip per element
-        constexpr int NLD = (WIN * WIN + 255) / 256;
+        constexpr int NLD = (WINH * WIN + 255) / 256;
         float stage[NLD];
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
-            const int i = min(tid + 256 * q, WIN * WIN - 1);
+            const int i = min(tid + 256 * q, WINH * WIN - 1);
             const int r = i / WIN, c = i - r * WIN;
             int yy = min(max(y0 + r - R, -R), h - 1 + R), xx = min(max(x0 + c - R, -R), w - 1 + R);
             yy = yy < 0 ? -yy : yy; yy = yy >= h ? 2 * h - 2 - yy : yy;
@@ -162,10 +166,10 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
         for (int q = 0; q < NLD; ++q) {
             const int i = tid + 256 * q;
             const int r = i / WIN, c = i - r * WIN;
-            if (i < WIN * WIN) s_src[r * SP + c] = stage[q];
+            if (i < WINH * WIN) s_src[r * SP + c] = stage[q];
         }
     } else {
-        for (int i = tid; i < WIN * WIN; i += 256) {
+        for (int i = tid; i < WINH * WIN; i += 256) {
             const int r = i / WIN, c = i - r * WIN;
             s_src[r * SP + c] = s[(size_t)s_refl(y0 + r - R, h) * w + s_refl(x0 + c - R, w)];
         }
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
     // pairs P[m] = (v[m], v[m+4]) so that every multiply and add is a v_pk_*_f32 (two IEEE f32
     // operations per instruction, same rounding as the scalar ones: no contraction).
     // row pass: item = (window row, group of 8 columns)
-    for (int it = tid; it < WIN * 8; it += 256) {
+    for (int it = tid; it < WINH * 8; it += 256) {
         const int r = it >> 3, g = it & 7;
         const float *row = s_src + r * SP + 8 * g;
         f32x2 P[4 + 2 * R];
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
     __syncthreads();
     // column pass: item = (column, group of 8 rows)
     const long long ob = (long long)blockIdx.y * dstride, db = (long long)blockIdx.y * dogstride;
-    for (int it = tid; it < 64 * 8; it += 256) {
+    for (int it = tid; it < 64 * (TH / 8); it += 256) {
         const int c = it & 63, g = it >> 6;
         const float *col = s_tmp + (8 * g) * 64 + c;
         f32x2 P[4 + 2 * R];
@@ -274,18 +278,18 @@ __device__ __forceinline__ float dpp_wave_shl1(float v)     // lane i <- lane i+
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
 }
-__global__ __launch_bounds__(256) void sift_extrema_mask_kernel(const float *__restrict__ dog, SiftDev dv, const SiftXTile *__restrict__ tiles,
+__global__ __launch_bounds__(256) void sift_extrema_mask_kernel(const float *__restrict__ gauss, SiftDev dv, const SiftXTile *__restrict__ tiles,
                                                                  unsigned long long *__restrict__ mask, int *__restrict__ band_cnt)
 {
     __shared__ float s_d[3][(SX_TH + 2) * SX_P];
     const SiftXTile t = tiles[blockIdx.x];
     const int img = blockIdx.y, o = t.o, w = dv.w[o], h = dv.h[o], x0 = t.x0, y0 = t.y0;
     const long long n = (long long)w * h;
-    const float *d = dog + (long long)img * dv.dstride + dv.doff[o];
+    const float *d = gauss + (long long)img * dv.gstride + dv.goff[o];     // Gaussian levels; DoG l = G[l+1] - G[l]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int NEL = (SX_TH + 2) * (SX_TW + 2), NLD = (NEL + 255) / 256;
-    float stage[NLD];
-    auto fetch = [&](int layer) {               // all loads of a layer in flight
+    float stage[NLD], prevg[NLD];
+    auto fetch = [&](int layer) {               // all loads of a Gaussian level in flight
         const float *src = d + layer * n;
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
@@ -295,24 +299,30 @@ __global__ __launch_bounds__(256) void sift_extrema_mask_kernel(const float *__r
             stage[q] = src[(size_t)y * w + x];
         }
     };
-    auto commit = [&](int slot) {
+    auto keep = [&]() {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) prevg[q] = stage[q];
+    };
+    auto commit = [&](int slot) {               // DoG = this level - the level below, into an LDS plane
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
             const int i = tid + 256 * q;
             const int r = i / (SX_TW + 2), c = i - r * (SX_TW + 2);
-            if (i < NEL) s_d[slot][r * SX_P + c] = stage[q];
+            if (i < NEL) s_d[slot][r * SX_P + c] = stage[q] - prevg[q];
+            prevg[q] = stage[q];
         }
     };
-    fetch(0); commit(0);
-    fetch(1); commit(1);
-    fetch(2);
+    fetch(0); keep();
+    fetch(1); commit(0);
+    fetch(2); commit(1);
+    fetch(3);
     unsigned long long *mk = mask + (long long)img * dv.bmstride + dv.bmoff[o];
     int *bc = band_cnt + (long long)img * dv.nbands + dv.band0[o];
     const int hcol = lane < 32 ? 0 : SX_TW + 1;            // halo column this lane can stand in for
     for (int l = 1; l <= S_NOL; ++l) {
         commit((l + 1) % 3);
         __syncthreads();
-        if (l < S_NOL) fetch(l + 2);                        // next layer's loads fly during the tests
+        if (l < S_NOL) fetch(l + 3);                        // next level's loads fly during the tests
         const float *lo = s_d[(l - 1) % 3], *mid = s_d[l % 3], *hi = s_d[(l + 1) % 3];
         // rolling per-row layer max/min: own column and halo column
         float pmx[3], pmn[3], hmx[3], hmn[3];
@@ -402,8 +412,14 @@ __global__ __launch_bounds__(256) void sift_extrema_emit_kernel(const unsigned l
 }
 
 // ------------------------------------------------------- refine + orientation
-struct DogCtx { const float *d; long long n; int w, h; };
-__device__ __forceinline__ float DOGV(const DogCtx &c, int l, int r, int x) { return c.d[l * c.n + (size_t)r * c.w + x]; }
+// DoG layer l = G[l+1] - G[l], formed where it is consumed (the DoG pyramid is never stored: 20 B per octave pixel less
+// HBM traffic in the blur, 221 MB per HD image less workspace); same f32 subtraction as a stored DoG
+struct DogCtx { const float *d; long long n; int w, h; };      // d = Gaussian levels of the octave
+__device__ __forceinline__ float DOGV(const DogCtx &c, int l, int r, int x)
+{
+    const size_t p = (size_t)r * c.w + x;
+    return c.d[(l + 1) * c.n + p] - c.d[l * c.n + p];
+}
 
 __device__ static bool sift_adjust(const DogCtx &c, int &layer, int &r, int &x, float &xi_, float &xr_, float &xc_, float &contr_)
 {
@@ -478,7 +494,7 @@ __device__ static bool sift_adjust(const DogCtx &c, int &layer, int &r, int &x, 
 // orientation histogram is a per-survivor reduction (one WAVE per survivor).  Survivors and raw
 // keypoints are appended through integer atomics; their order is irrelevant (sorted afterwards).
 #define SURV_W 8        // floats per survivor record: packed(o,l,r,c), xi, xr, xc, contr
-__global__ __launch_bounds__(256) void sift_adjust_kernel(const float *__restrict__ dog, SiftDev dv,
+__global__ __launch_bounds__(256) void sift_adjust_kernel(const float *__restrict__ gauss, SiftDev dv,
                                                            const unsigned *__restrict__ seeds, const int *__restrict__ nseeds,
                                                            float *__restrict__ surv, int *__restrict__ nsurv)
 {
@@ -488,7 +504,7 @@ __global__ __launch_bounds__(256) void sift_adjust_kernel(const float *__restric
     const int o = sd >> 28;
     int l = (sd >> 26) & 3, r = (sd >> 13) & 0x1FFF, c = sd & 0x1FFF;
     const int w = dv.w[o], h = dv.h[o];
-    DogCtx dc = {dog + (long long)img * dv.dstride + dv.doff[o], (long long)w * h, w, h};
+    DogCtx dc = {gauss + (long long)img * dv.gstride + dv.goff[o], (long long)w * h, w, h};
     float xi = 0, xr = 0, xc = 0, contr = 0;
     if (!sift_adjust(dc, l, r, c, xi, xr, xc, contr)) return;
     const int slot = atomicAdd(&nsurv[img], 1);               // <= nseeds <= seed_cap
@@ -988,7 +1004,6 @@ int rpe_sift_create(rpe_handle *h)
     if (!xt.empty()) SCHK(hipMemcpy(S->d_xtiles, xt.data(), sizeof(SiftXTile) * xt.size(), hipMemcpyHostToDevice));
     SCHK(hipMalloc(&S->d_xmask, sizeof(unsigned long long) * NI * dv.bmstride));
     SCHK(hipMalloc(&S->d_gauss, sizeof(float) * NI * dv.gstride));
-    SCHK(hipMalloc(&S->d_dog, sizeof(float) * NI * dv.dstride));
     SCHK(hipMalloc(&S->d_tmp, sizeof(float) * NI * dv.tstride * 2));
     SCHK(hipMalloc(&S->d_band_cnt, sizeof(int) * NI * dv.nbands));
     SCHK(hipMalloc(&S->d_band_off, sizeof(int) * NI * dv.nbands));
@@ -1022,8 +1037,9 @@ template <int R>
 static void sift_blur_launch(rpe_handle *h, const float *src, long long sstride, float *dst, long long dstride, float *dog,
                              long long dogstride, int w, int hh, int kid, int n_img)
 {
-    const int tcols = (w + 63) / 64, ntiles = tcols * ((hh + 63) / 64);
-    hipLaunchKernelGGL(sift_blur_fused_kernel<R>, dim3(ntiles, n_img), dim3(256), 0, h->stream, src, sstride, dst, dstride, dog, dogstride,
+    constexpr int TH = R >= 8 ? 32 : 64;
+    const int tcols = (w + 63) / 64, ntiles = tcols * ((hh + TH - 1) / TH);
+    hipLaunchKernelGGL((sift_blur_fused_kernel<R, TH>), dim3((ntiles + 7) / 8 * 8, n_img), dim3(256), 0, h->stream, src, sstride, dst, dstride, dog, dogstride,
                        w, hh, kid, tcols, ntiles);
 }
 
@@ -1076,13 +1092,13 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
                                S->d_gauss + dv.goff[o], dv.gstride, dv.w[o - 1], w, hh);
         for (int i = 1; i < S_NG; ++i)
             sift_blur(h, S->d_gauss + dv.goff[o] + (i - 1) * pn, dv.gstride, S->d_gauss + dv.goff[o] + i * pn, dv.gstride,
-                      S->d_dog + dv.doff[o] + (i - 1) * pn, dv.dstride, w, hh, i, n);
+                      nullptr, 0, w, hh, i, n);
     }
     // 3. seeds (count, scan, emit)
     MARK(h, RPE_STAGE_FAST);
     hipMemsetAsync(S->d_band_cnt, 0, sizeof(int) * (size_t)n * dv.nbands, h->stream);
     if (S->n_xtiles)
-        hipLaunchKernelGGL(sift_extrema_mask_kernel, dim3(S->n_xtiles, n), dim3(256), 0, h->stream, (const float *)S->d_dog, dv,
+        hipLaunchKernelGGL(sift_extrema_mask_kernel, dim3(S->n_xtiles, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
                            (const SiftXTile *)S->d_xtiles, S->d_xmask, S->d_band_cnt);
     hipLaunchKernelGGL(sift_band_scan_kernel, dim3(n), dim3(256), 0, h->stream, (const int *)S->d_band_cnt, S->d_band_off, S->d_nseeds, dv);
     hipLaunchKernelGGL(sift_extrema_emit_kernel, dim3((dv.nbands + 3) / 4, n), dim3(256), 0, h->stream, (const unsigned long long *)S->d_xmask, dv,
@@ -1092,7 +1108,7 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
     hipMemsetAsync(S->d_overflow, 0, sizeof(int) * n, h->stream);
     MARK(h, RPE_STAGE_NMS); MARK(h, RPE_STAGE_SELECT);
     hipMemsetAsync(S->d_nsurv, 0, sizeof(int) * n, h->stream);
-    hipLaunchKernelGGL(sift_adjust_kernel, dim3((dv.seed_cap + 255) / 256, n), dim3(256), 0, h->stream, (const float *)S->d_dog, dv,
+    hipLaunchKernelGGL(sift_adjust_kernel, dim3((dv.seed_cap + 255) / 256, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
                        (const unsigned *)S->d_seeds, (const int *)S->d_nseeds, S->d_surv, S->d_nsurv);
     MARK(h, RPE_STAGE_HARRIS);
     hipLaunchKernelGGL(sift_orient_kernel, dim3(2048, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
