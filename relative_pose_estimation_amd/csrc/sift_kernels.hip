@@ -279,10 +279,14 @@ __device__ __forceinline__ float dpp_wave_shl1(float v)     // lane i <- lane i+
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
 }
 __global__ __launch_bounds__(256) void sift_extrema_mask_kernel(const float *__restrict__ gauss, SiftDev dv, const SiftXTile *__restrict__ tiles,
-                                                                 unsigned long long *__restrict__ mask, int *__restrict__ band_cnt)
+                                                                 unsigned long long *__restrict__ mask, int *__restrict__ band_cnt, int ntiles)
 {
     __shared__ float s_d[3][(SX_TH + 2) * SX_P];
-    const SiftXTile t = tiles[blockIdx.x];
+    // XCD-aware order (workgroups are dealt round-robin over 8 XCDs): a contiguous raster run of tiles per XCD, so the
+    // 128-B lines straddling two tiles (264-B tile rows) and the halo rows are fetched into one L2, not two
+    const int ti = ((blockIdx.x & 7) * ((ntiles + 7) >> 3)) + (blockIdx.x >> 3);
+    if (ti >= ntiles) return;
+    const SiftXTile t = tiles[ti];
     const int img = blockIdx.y, o = t.o, w = dv.w[o], h = dv.h[o], x0 = t.x0, y0 = t.y0;
     const long long n = (long long)w * h;
     const float *d = gauss + (long long)img * dv.gstride + dv.goff[o];     // Gaussian levels; DoG l = G[l+1] - G[l]
@@ -1098,8 +1102,8 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
     MARK(h, RPE_STAGE_FAST);
     hipMemsetAsync(S->d_band_cnt, 0, sizeof(int) * (size_t)n * dv.nbands, h->stream);
     if (S->n_xtiles)
-        hipLaunchKernelGGL(sift_extrema_mask_kernel, dim3(S->n_xtiles, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
-                           (const SiftXTile *)S->d_xtiles, S->d_xmask, S->d_band_cnt);
+        hipLaunchKernelGGL(sift_extrema_mask_kernel, dim3((S->n_xtiles + 7) / 8 * 8, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
+                           (const SiftXTile *)S->d_xtiles, S->d_xmask, S->d_band_cnt, S->n_xtiles);
     hipLaunchKernelGGL(sift_band_scan_kernel, dim3(n), dim3(256), 0, h->stream, (const int *)S->d_band_cnt, S->d_band_off, S->d_nseeds, dv);
     hipLaunchKernelGGL(sift_extrema_emit_kernel, dim3((dv.nbands + 3) / 4, n), dim3(256), 0, h->stream, (const unsigned long long *)S->d_xmask, dv,
                        (const int *)S->d_band_cnt, (const int *)S->d_band_off, S->d_seeds);
