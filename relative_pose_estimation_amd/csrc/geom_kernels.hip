@@ -4,13 +4,17 @@
 // (reference src/core/pose_estimator.py:522-527) and cv2.recoverPose(E, pts1, pts2, K)
 // (:533).  Sequential OpenCV semantics (calib3d/ptsetreg.cpp RANSACPointSetRegistrator::run:
 // fixed RNG stream, "strictly more inliers wins", adaptive niters) are reproduced on a
-// parallel machine by evaluating RANSAC_CHUNK iterations at a time and replaying the
-// update rule serially over the per-model inlier counts:
+// parallel machine by evaluating a chunk of iterations at a time (64, 64, 128, 256, 512) and replaying
+// the update rule over the per-model inlier counts:
 //   ransac_prepare : normalise points with K (f64), reset per-pair state
-//   ransac_solve   : one lane = one minimal sample -> Nister five-point solve (f64)
-//   ransac_score   : one workgroup per pair; lanes stride over the matches, Sampson
-//                    error (f64 -> f32 compare), wave-reduced inlier counts per model,
-//                    then lane 0 replays the sequential update rule for the chunk
+//   ransac_poly    : one lane = one minimal sample: null space, 10x20 elimination in lane-interleaved
+//                    LDS, determinant polynomial of degree 10 (f64)
+//   ransac_roots   : 16 lanes per sample: lane = bracketing interval of the derivative chain, safeguarded
+//                    Newton, ballot/shuffle compaction; back-substitution lane = root -> up to 10 models
+//   ransac_score   : workgroup per (pair, 64 iterations), wave per model: Sampson error (f64 -> f32
+//                    compare) over the matches in LDS, shuffle-reduced inlier counts
+//   ransac_update  : wave per pair: the sequential "strictly more inliers wins / niters shrinks / stop at
+//                    niters" rule as prefix-max and prefix-min scans (bit-identical termination)
 //   ransac_mask    : inlier mask of the winning model (stage API only)
 //   recover_pose   : 3x3 one-sided Jacobi SVD, 4 candidate poses, per-point 4x4 Jacobi
 //                    DLT triangulation + cheirality vote, wave-reduced counts
@@ -144,64 +148,6 @@ __device__ __forceinline__ double refine_root_s(const double (&p)[11], const dou
         if (f > 0.0) xh = rts; else xl = rts;
     }
     return rts;
-}
-
-template <int K>
-__device__ __forceinline__ int roots_level(const double (&c)[11], const double *crit, int nr_prev, double *out)
-{
-    double p[11], dp[11];
-#pragma unroll
-    for (int i = 0; i <= 10; ++i) p[i] = c[i];
-#pragma unroll
-    for (int kk = 10; kk > K; --kk)
-#pragma unroll
-        for (int i = 0; i < kk; ++i) p[i] = p[i + 1] * (double)(i + 1);
-#pragma unroll
-    for (int i = 0; i < K; ++i) dp[i] = p[i + 1] * (double)(i + 1);
-    double mx = 0.;
-#pragma unroll
-    for (int i = 0; i < K; ++i) { double a = fabs(p[i]); if (a > mx) mx = a; }
-    double R = 1. + mx / fabs(p[K]);
-    if (!(R < 1e12)) R = 1e12;
-    int nout = 0;
-    for (int iv = 0; iv <= nr_prev; ++iv) {
-        double a = (iv == 0) ? -R : crit[iv - 1];
-        double b = (iv == nr_prev) ? R : crit[iv];
-        if (a < -R) a = -R;
-        if (b > R) b = R;
-        if (!(a < b)) continue;
-        int sa = horner_s<K>(p, a) > 0., sb = horner_s<K>(p, b) > 0.;
-        if (sa == sb) continue;
-        out[nout++] = refine_root_s<K>(p, dp, a, b, sa);
-    }
-    return nout;
-}
-
-__device__ static int poly_real_roots10(const double (&c)[11], double *roots)
-{
-    double ra[11], rb[11];
-    {
-        double p[11];
-#pragma unroll
-        for (int i = 0; i <= 10; ++i) p[i] = c[i];
-#pragma unroll
-        for (int kk = 10; kk > 1; --kk)
-#pragma unroll
-            for (int i = 0; i < kk; ++i) p[i] = p[i + 1] * (double)(i + 1);
-        ra[0] = -p[0] / p[1];
-    }
-    int n = 1;
-    n = roots_level<2>(c, ra, n, rb);
-    n = roots_level<3>(c, rb, n, ra);
-    n = roots_level<4>(c, ra, n, rb);
-    n = roots_level<5>(c, rb, n, ra);
-    n = roots_level<6>(c, ra, n, rb);
-    n = roots_level<7>(c, rb, n, ra);
-    n = roots_level<8>(c, ra, n, rb);
-    n = roots_level<9>(c, rb, n, ra);
-    n = roots_level<10>(c, ra, n, rb);
-    for (int i = 0; i < n; ++i) roots[i] = rb[i];
-    return n;
 }
 
 // Nister five-point solver (five-point.cpp EMEstimatorCallback::runKernel restated;
@@ -348,57 +294,6 @@ __device__ static int five_point_poly(const double *x1, const double *x2, double
     for (int m = 0; m < 4; ++m) for (int e = 0; e < 9; ++e) rec[(50 + m * 9 + e) * 64] = Eb[m][e];
     rec[86 * 64] = (double)n;
     return 1;
-}
-
-// Part B (register-resident, no LDS): real roots of the degree-10 polynomial, back-substitution.
-__device__ static int five_point_roots(const double *rec, double *E_out)
-{
-    double c10[11];
-    for (int i = 0; i < 11; ++i) c10[i] = rec[i * 64];
-    const int n = (int)rec[86 * 64];
-    double Bx[3][4], By[3][4], B1[3][5];
-    double roots[10];
-    int nroots = (n == 10) ? poly_real_roots10(c10, roots) : poly_real_roots_generic(c10, n, roots);
-    if (nroots > 0) {
-        for (int i = 0; i < 3; ++i) {
-            for (int k = 0; k < 4; ++k) { Bx[i][k] = rec[(11 + i * 4 + k) * 64]; By[i][k] = rec[(23 + i * 4 + k) * 64]; }
-            for (int k = 0; k < 5; ++k) B1[i][k] = rec[(35 + i * 5 + k) * 64];
-        }
-    }
-    int count = 0;
-    for (int ri = 0; ri < nroots && count < 10; ++ri) {
-        double z = roots[ri];
-        double bz[3][3];
-        for (int i = 0; i < 3; ++i) {
-            bz[i][0] = ((Bx[i][3] * z + Bx[i][2]) * z + Bx[i][1]) * z + Bx[i][0];
-            bz[i][1] = ((By[i][3] * z + By[i][2]) * z + By[i][1]) * z + By[i][0];
-            bz[i][2] = (((B1[i][4] * z + B1[i][3]) * z + B1[i][2]) * z + B1[i][1]) * z + B1[i][0];
-        }
-        double bestn = -1., xv0 = 0., xv1 = 0., xv2 = 0.;
-        for (int i = 0; i < 3; ++i) {
-            int r0 = i, r1 = (i + 1) % 3;
-            double cx = bz[r0][1] * bz[r1][2] - bz[r0][2] * bz[r1][1];
-            double cy = bz[r0][2] * bz[r1][0] - bz[r0][0] * bz[r1][2];
-            double cz = bz[r0][0] * bz[r1][1] - bz[r0][1] * bz[r1][0];
-            double nn = cx * cx + cy * cy + cz * cz;
-            if (nn > bestn) { bestn = nn; xv0 = cx; xv1 = cy; xv2 = cz; }
-        }
-        if (!(bestn > 0.)) continue;
-        double inv = 1. / sqrt(bestn);
-        double w = xv2 * inv;
-        if (fabs(w) < 1e-10) continue;
-        double x = xv0 / xv2, y = xv1 / xv2;
-        double Ev[9], nrm = 0.;
-        for (int e = 0; e < 9; ++e) {
-            Ev[e] = ((rec[(50 + e) * 64] * x + rec[(59 + e) * 64] * y) + rec[(68 + e) * 64] * z) + rec[(77 + e) * 64];
-            nrm += Ev[e] * Ev[e];
-        }
-        nrm = sqrt(nrm);
-        if (!(nrm > 0.)) continue;
-        for (int e = 0; e < 9; ++e) E_out[count * 9 + e] = Ev[e] / nrm;
-        ++count;
-    }
-    return count;
 }
 
 // ---------------------------------------------------------------- prepare

@@ -6,16 +6,18 @@
 // order (contraction off, deterministic exp/sincos, fixed partial-sum trees), so results
 // compare bit for bit.  Kernel groups (all images of the batch per launch):
 //   upsample  : u8 -> f32, 2x INTER_LINEAR
-//   blur      : separable Gaussian (row pass through an LDS segment, column pass), reflect-101
+//   blur      : fused separable Gaussian per 64 x {64,32} tile (window + row-pass plane in LDS, packed-f32 taps),
+//               reflect-101; an unfused row/column pair remains as the fallback for other tap counts
 //   halve     : INTER_NEAREST octave decimation
-//   dog       : difference of neighbouring Gaussian levels
-//   extrema   : 26-neighbour test; two passes (count, emit) over row bands give a raster-
-//               ordered seed list without a serial scan of the image
-//   refine    : one wave per seed: adjustLocalExtrema on lane 0, orientation histogram on all
-//               64 lanes (8 LDS rounds x 8 lanes keep the per-slot summation order), peaks
-//   sort      : bitonic sort of the raw keypoints by KeyPoint_LessThan (one workgroup / image)
+//   (DoG)     : never stored: layer l = G[l+1] - G[l] is formed where it is consumed (extrema scan, adjust)
+//   extrema   : tiled 26-neighbour test (rolling LDS layers, separable max/min, DPP) -> 1-bit hit mask + one
+//               counter per (octave, layer, row) band; parallel band scan; wave-per-row emit = raster-ordered seeds
+//   adjust    : one lane per seed: adjustLocalExtrema (contrast / edge tests); survivors appended by integer atomics
+//   orient    : one wave per survivor: 36-bin orientation histogram (8 LDS rounds x 8 lanes keep the per-slot
+//               summation order), peaks -> raw keypoints
+//   sort      : response prefilter, bitonic sort of the raw keypoints by KeyPoint_LessThan (one workgroup / image)
 //   finalize  : duplicate removal, retainBest(nfeatures) by radix select, ordered compaction
-//   describe  : one wave per keypoint, 4x4x8 trilinear histogram in 8 interleaved partials
+//   describe  : one wave per keypoint, 4x4x8 trilinear histogram in 8 interleaved partials, lane = (slot, corner)
 #include "rpe_internal.h"
 #include "rpe_devmath.h"
 #include <float.h>
