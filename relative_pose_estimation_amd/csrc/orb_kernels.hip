@@ -2,16 +2,16 @@
 //
 // Replaces cv2.ORB_create(nfeatures, 1.1, 12, fastThreshold=15, HARRIS_SCORE)
 // .detectAndCompute(image, None)  (reference src/core/pose_estimator.py:85-91,:108).
-// Stages (one kernel group each, all images of the batch per launch):
-//   pyramid  : INTER_LINEAR_EXACT chain, 8.8 fixed point            (integer)
-//   fast     : FAST-9/16 score map, LDS tile + in-tile candidate compaction
-//   nms      : 3x3 NMS + 31-px border filter + per-level score histogram
-//   select   : retainBest(2*quota) threshold from the histogram, raster-ordered compaction
+// Kernels (all images of the batch per launch; the stage names are the hipEvent slots of rpe_get_stage_ms):
+//   pyramid  : pyr_resize x11: INTER_LINEAR_EXACT chain, 8.8 fixed point, 128x64 tiles, source window in LDS
+//   fast     : fast_nms: FAST-9/16 score + 3x3 NMS + 31-px border filter + per-level score histogram, fused;
+//              tiles cover the border-filtered region only ("nms" slot is empty)
+//   select   : select_candidates: retainBest(2*quota) threshold from the histogram, raster-ordered compaction
 //   harris   : 7x7 Harris response per candidate (f32, op order = oracle)
-//   keypoints: retainBest(quota) by radix select, raster-ordered compaction, level-major
-//   angle    : intensity-centroid moments, one wave per keypoint, fastAtan2
-//   blur     : separable fixed-point Gaussian 7x7, LDS tile
-//   describe : steered BRIEF, 32 lanes per keypoint (one descriptor byte per lane)
+//   keypoints: select_keypoints: retainBest(quota), one wave per level, raster-ordered compaction, level-major
+//   angle    : orient_describe: one wave per keypoint: patch in LDS -> intensity-centroid angle (fastAtan2) ->
+//              Gaussian 7x7 on the patch -> 256-bit steered BRIEF ("blur" / "describe" slots are empty; the
+//              whole-level blur kernel below only serves rpe_orb_debug_fetch)
 // Everything is integer or mirrored-order f32, so results equal the CPU oracle bit for bit.
 #include "rpe_internal.h"
 #include "rpe_devmath.h"
