@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
                                                         const RpeTile *__restrict__ tiles, int ntiles)
 {
     __shared__ unsigned s_in[72 * 18];              // pixels  y0-4 .. y0+67, x0-4 .. x0+67
-    __shared__ unsigned s_sc[FS_ROWS * 18];         // scores  y0-1 .. y0+64, x0-4 .. x0+67
-    __shared__ unsigned s_nms[64 * 16];             // output tile
+    __shared__ __attribute__((aligned(16))) unsigned s_sc[FS_ROWS * 18];   // scores  y0-1 .. y0+64, x0-4 .. x0+67
+    __shared__ __attribute__((aligned(16))) unsigned s_nms[64 * 16];       // output tile
     __shared__ unsigned short s_cand[FS_ROWS * 72];
     __shared__ unsigned s_hist[256];
     __shared__ int s_ncand;
@@ -181,22 +181,26 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
     const uint8_t *src = pyr + ibase;
     if (tid == 0) s_ncand = 0;
     s_hist[tid] = 0;
-    {   // all tile loads in flight before the first LDS store
-        constexpr int NLD = (72 * 18 + 255) / 256;
-        unsigned stage[NLD];
+    {   // all tile loads in flight before the first LDS store.  lane -> fixed dword column (tid % 18) and rows
+        // tid / 18 + 14 q: one column clamp and one division per tile instead of one per load
+        const int lc = tid % 18, lr = tid / 18;
+        const int lx = min(max(x0 - 4 + 4 * lc, 0), pitch - 4);
+        unsigned stage[6];
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) {
-            const int i = min(tid + 256 * q, 72 * 18 - 1);
-            const int r = i / 18, c = i - r * 18;
+        for (int q = 0; q < 6; ++q) {
+            const int r = min(lr + 14 * q, 71);
             const int y = min(max(y0 - 4 + r, 0), hgt - 1);
-            const int x = min(max(x0 - 4 + 4 * c, 0), pitch - 4);
-            stage[q] = *(const unsigned *)(src + (long long)y * pitch + x);
+            stage[q] = *(const unsigned *)(src + (long long)y * pitch + lx);
         }
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) { const int i = tid + 256 * q; if (i < 72 * 18) s_in[i] = stage[q]; }
+        for (int q = 0; q < 6; ++q) { const int r = lr + 14 * q; if (tid < 252 && r < 72) s_in[r * 18 + lc] = stage[q]; }
     }
-    for (int i = tid; i < FS_ROWS * 18; i += 256) s_sc[i] = 0;
-    for (int i = tid; i < 64 * 16; i += 256) s_nms[i] = 0;
+    {   // zero the score tile and the output tile with 16-B LDS stores
+        uint4 *z1 = (uint4 *)s_sc, *z2 = (uint4 *)s_nms;
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < FS_ROWS * 18 / 4; i += 256) z1[i] = z;
+        z2[tid] = z;                                               // 64 * 16 dwords = 256 x 16 B
+    }
     __syncthreads();
     // ---- phase 1 (packed 16-bit SWAR: even / odd pixels of the dword group in one VGPR each)
     // lane -> fixed dword column c (18 per row) and rows r0, r0+14, ... : the x-validity mask is
