@@ -26,10 +26,23 @@ __constant__ signed char c_disc[768 * 2];   // (u,v) offsets of the radius-15 di
 __constant__ int c_ndisc;
 __constant__ signed char c_circ[16 * 2] = {0,3, 1,3, 2,2, 3,1, 3,0, 3,-1, 2,-2, 1,-3, 0,-3, -1,-3, -2,-2, -3,-1, -3,0, -3,1, -2,2, -1,3};
 
+// the same disc as packed-u8 dot-product weights: item (row v = -15..15, dword j = 0..7) covers u = -16 + 4j .. +3;
+// .x = 1 per in-disc byte, .y = (u + 16) per in-disc byte (0 elsewhere)
+__constant__ uint2 c_discw[31 * 8];
+
 void rpe_orb_upload_disc(const signed char *disc, int n)
 {
     hipMemcpyToSymbol(HIP_SYMBOL(c_disc), disc, (size_t)n * 2);
     hipMemcpyToSymbol(HIP_SYMBOL(c_ndisc), &n, sizeof(int));
+    uint2 wt[31 * 8];
+    for (int i = 0; i < 31 * 8; ++i) wt[i] = make_uint2(0u, 0u);
+    for (int i = 0; i < n; ++i) {
+        const int u = disc[2 * i], v = disc[2 * i + 1];
+        const int j = (u + 16) >> 2, b = (u + 16) & 3;
+        wt[(v + 15) * 8 + j].x |= 1u << (8 * b);
+        wt[(v + 15) * 8 + j].y |= (unsigned)(u + 16) << (8 * b);
+    }
+    hipMemcpyToSymbol(HIP_SYMBOL(c_discw), wt, sizeof(wt));
 }
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an
@@ -645,28 +658,42 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
     unsigned *raw = s_raw[wv], *hb = s_hb[wv];
     if (active) {
         const uint8_t *src = pyr + (long long)img * lay.stride + L.off + (long long)(y0 - KP_R) * pitch + xal;
-        constexpr int NLD = (KP_ROWS * KP_RAW_DW + 63) / 64;
-        unsigned stage[NLD];
+        // lane -> fixed dword column (lane % 12) and rows lane / 12 + 5 q (60 lanes x 9 loads = 45 x 12 dwords)
+        const int lc = lane % KP_RAW_DW, lr = lane / KP_RAW_DW;
+        unsigned stage[9];
+        const uint8_t *col = src + 4 * lc;
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) {
-            const int i = min(lane + 64 * q, KP_ROWS * KP_RAW_DW - 1);
-            const int r = i / KP_RAW_DW, c = i - r * KP_RAW_DW;
-            stage[q] = *(const unsigned *)(src + (long long)r * pitch + 4 * c);
+        for (int q = 0; q < 9; ++q) stage[q] = *(const unsigned *)(col + (long long)min(lr + 5 * q, KP_ROWS - 1) * pitch);
+        if (lane < 60) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) raw[(lr + 5 * q) * KP_RAW_DW + lc] = stage[q];
         }
-#pragma unroll
-        for (int q = 0; q < NLD; ++q) { const int i = lane + 64 * q; if (i < KP_ROWS * KP_RAW_DW) raw[i] = stage[q]; }
     }
     __syncthreads();
     float a = 1.f, b = 0.f;
     if (active) {
         // ---- orb.cpp ICAngles: integer moments over the disc, reduced with wave shuffles
         const uint8_t *rb = (const uint8_t *)raw + KP_R * (KP_RAW_DW * 4) + off0 + KP_R;   // centre pixel
+        // integer sums, so any summation order gives the oracle's moments: 4 disc pixels per packed-u8 dot product
         int m10 = 0, m01 = 0;
-        const int nd = c_ndisc;
-        for (int i = lane; i < nd; i += 64) {
-            int u = c_disc[2 * i], v = c_disc[2 * i + 1];
-            int val = rb[v * (KP_RAW_DW * 4) + u];
-            m10 += u * val; m01 += v * val;
+        {
+            const unsigned *rw = raw + (KP_R - 15) * KP_RAW_DW;                  // patch row of v = -15
+            const int bo = off0 + KP_R - 16;                                        // byte column of u = -16 (>= 6)
+            const int sh = bo & 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int it = lane + 64 * q;                                       // item = (v + 15) * 8 + j
+                if (it < 31 * 8) {
+                    const int vr = it >> 3, j = it & 7;
+                    const uint2 wt = c_discw[it];
+                    const unsigned *pw = rw + vr * KP_RAW_DW + ((bo >> 2) + j);
+                    const unsigned px = __builtin_amdgcn_alignbyte(pw[1], pw[0], sh);
+                    const int s1 = (int)__builtin_amdgcn_udot4(px, wt.x, 0u, false);
+                    const int su = (int)__builtin_amdgcn_udot4(px, wt.y, 0u, false);
+                    m10 += su - 16 * s1;
+                    m01 += (vr - 15) * s1;
+                }
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
