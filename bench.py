@@ -53,8 +53,8 @@ def stage_bytes(stage, W, H, pyr_px, nkp, mm, method="ORB"):
     if method == "SIFT":
         px = sum(w * h for w, h in sift_octaves(W, H))
         per_image = {
-            "pyramid": img + (6 + 5) * 4 * px,           # read the u8 image, write 6 Gaussian + 5 DoG f32 levels per octave
-            "fast": 5 * 4 * px + 3 * px // 8,            # extrema scan: read every DoG level once, write the 1-bit hit mask
+            "pyramid": img + 6 * 4 * px,                 # read the u8 image, write the 6 Gaussian f32 levels per octave (DoG is never stored)
+            "fast": 6 * 4 * px + 3 * px // 8,            # extrema scan: read every Gaussian level once (DoG on the fly), write the 1-bit hit mask
             "select": 27 * 4 * nkp * 8,                  # adjustLocalExtrema: 3x3x3 DoG block per seed (~8 seeds per kept keypoint)
             "harris": 4 * 4 * 400 * nkp,                 # orientation: 4 gradient taps x ~400 window samples per keypoint
             "keypoints": 24 * nkp * 4,
