@@ -171,10 +171,13 @@ def test_error_statuses(capi, K_vga):
     pe.close()
 
 
-@pytest.mark.parametrize("W,H,nf", [(848, 478, 4000), (1920, 1080, 2000), (640, 480, 4000)])
+@pytest.mark.parametrize("W,H,nf", [(848, 478, 4000), (1920, 1080, 2000), (640, 480, 4000),
+                                    (130, 98, 300), (333, 257, 500), (1001, 203, 1500), (96, 96, 100)])
 def test_other_sizes_and_reference_defaults(capi, oracle, W, H, nf):
     """reference defaults (nfeatures=4000, pose_estimator.py:25), the phone-data frame size
-    (848x478: pitch != width) and the Salah HD size (BASELINE config 3 resolution)."""
+    (848x478: pitch != width), the Salah HD size (BASELINE config 3 resolution), and awkward sizes: the smallest
+    legal image (upper pyramid levels narrower than the 62-px border band: no FAST tiles at all there), odd widths,
+    a wide strip whose tiles are mostly partial."""
     from relative_pose_estimation_amd import synthetic, geometry
     K = geometry.default_camera_matrix(W, H)
     i1, i2, Rgt, _ = synthetic.make_batch(1, K, W, H, cfg=5)
