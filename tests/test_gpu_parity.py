@@ -394,3 +394,27 @@ def test_vp_refinement_call_path(capi, oracle):
     assert d2["vp_used"] == opt["cost_improved"]
     assert np.allclose(d2["R"] @ d2["R"].T, np.eye(3), atol=1e-9)
     pe.close(); pe2.close()
+
+
+@pytest.mark.parametrize("W,H", [(211, 157), (96, 130), (400, 97)])
+def test_sift_awkward_sizes(capi, oracle, W, H):
+    """partial 64x64 / 64x32 blur tiles, extrema tiles cut by the 5-px border, octaves smaller than a blur radius
+    (multi-reflection fallback path), mask words of rows that are not a multiple of 64 wide"""
+    from relative_pose_estimation_amd import synthetic, geometry
+    K = geometry.default_camera_matrix(W, H)
+    i1, i2, _, _ = synthetic.make_batch(1, K, W, H, cfg=7)
+    e = capi.Engine(W, H, max_batch=1, nfeatures=300, max_matches=200, feature_method=capi.FEATURE_SIFT, norm_type=capi.NORM_L2)
+    imgs = np.concatenate([i1, i2])
+    kps, desc, cnt = e.sift_detect_and_compute(imgs)
+    cap = e.kcap
+    for n in range(2):
+        go, dims = oracle.sift_gauss_pyramid(imgs[n])
+        gg = e.sift_debug_gauss(n)
+        assert gg.shape == go.shape and np.array_equal(gg.view(np.uint32), go.view(np.uint32)), "gaussian pyramid differs"
+        ko, do = oracle.sift_detect_and_compute(imgs[n], nfeatures=300, cap=cap)
+        assert cnt[n] == len(ko), (cnt[n], len(ko))
+        kg = kps[n, :cnt[n]]
+        for f in ("x", "y", "size", "angle", "response"):
+            assert np.array_equal(kg[f].view(np.uint32), ko[f].view(np.uint32)), f
+        assert np.array_equal(kg["octave"], ko["octave"]) and np.array_equal(desc[n, :cnt[n]], do)
+    e.close()
