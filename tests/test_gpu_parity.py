@@ -418,3 +418,17 @@ def test_sift_awkward_sizes(capi, oracle, W, H):
             assert np.array_equal(kg[f].view(np.uint32), ko[f].view(np.uint32)), f
         assert np.array_equal(kg["octave"], ko["octave"]) and np.array_equal(desc[n, :cnt[n]], do)
     e.close()
+
+
+def test_sift_stream_equals_pairwise(capi, oracle):
+    """the consecutive-frame stream with SIFT + L2 (pair p = image slots p, p+1 through the two L2 matcher kernels)"""
+    from relative_pose_estimation_amd import synthetic, geometry
+    K = geometry.default_camera_matrix(320, 240)
+    i1, i2, _, _ = synthetic.make_batch(2, K, 320, 240, cfg=6)
+    frames = np.stack([i1[0], i2[0], i1[1]])
+    e = capi.Engine(320, 240, max_batch=2, nfeatures=600, max_matches=300, feature_method=capi.FEATURE_SIFT, norm_type=capi.NORM_L2)
+    Rs, ts, inls, nms, sts = e.estimate_stream(frames, K)
+    Rp, tp, inlp, nmp, stp = e.estimate_batch(frames[:2], frames[1:], K)
+    assert np.array_equal(Rs, Rp) and np.array_equal(ts, tp) and np.array_equal(inls, inlp) and np.array_equal(nms, nmp) and np.array_equal(sts, stp)
+    assert sts[0] == 0
+    e.close()
