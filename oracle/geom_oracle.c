@@ -148,6 +148,25 @@ static double refine_root(const double *p, const double *dp, int k, double a, do
  * Nested-derivative isolation: the real roots of p^(k+1) split the line into
  * intervals on which p^(k) is monotone; every interval with a sign change
  * (s(v) = (v > 0)) holds exactly one root, refined by safeguarded Newton. */
+/* Root bound from binary exponents only (bit-reproducible on any machine): Fujiwara's
+ * |z| <= 2 max_i |a_{k-i}/a_k|^(1/i) with |a| < 2^(ilogb(a)+1), i.e. R = 2^(1 + max_i ceil((e_{k-i} - e_k + 1)/i)).
+ * Cauchy's 1 + max|a_i/a_k| put the outer brackets orders of magnitude beyond the roots and the safeguarded
+ * Newton spent most of its steps bisecting its way back. */
+static double root_bound(const double *p, int k)
+{
+    const int ek = ilogb(p[k]);
+    int emax = -100000;
+    for (int i = 0; i < k; ++i) {
+        if (p[i] == 0.) continue;
+        const int d = ilogb(p[i]) - ek + 1, m = k - i;
+        const int q = d >= 0 ? (d + m - 1) / m : -((-d) / m);      /* ceil(d / m) */
+        if (q > emax) emax = q;
+    }
+    double R = emax == -100000 ? 1. : ldexp(1., emax + 1);
+    if (!(R < 1e12)) R = 1e12;
+    return R;
+}
+
 static int poly_real_roots(const double *c, int n, double *roots)
 {
     double d[11][11];      /* d[k] = coefficients of the degree-k member of the derivative chain */
@@ -163,10 +182,7 @@ static int poly_real_roots(const double *c, int n, double *roots)
         const double *crit = rts[cur];
         double *out = rts[cur ^ 1];
         int nout = 0;
-        double mx = 0.;
-        for (int i = 0; i < k; ++i) { double a = fabs(p[i]); if (a > mx) mx = a; }
-        double R = 1. + mx / fabs(p[k]);
-        if (!(R < 1e12)) R = 1e12;
+        double R = root_bound(p, k);
         for (int iv = 0; iv <= nr_prev; ++iv) {
             double a = (iv == 0) ? -R : crit[iv - 1];
             double b = (iv == nr_prev) ? R : crit[iv];

@@ -72,6 +72,42 @@ __device__ static double refine_root(const double *p, const double *dp, int k, d
     return rts;
 }
 
+// Root bound from binary exponents only (same integers on CPU and GPU): Fujiwara's |z| <= 2 max_i |a_{k-i}/a_k|^(1/i)
+// with |a| < 2^(ilogb(a)+1): R = 2^(1 + max_i ceil((e_{k-i} - e_k + 1)/i)).  Cauchy's bound put the outer brackets
+// orders of magnitude beyond the roots and the safeguarded Newton bisected its way back (oracle: root_bound()).
+__device__ static double root_bound(const double *p, int k)
+{
+    const int ek = ilogb(p[k]);
+    int emax = -100000;
+    for (int i = 0; i < k; ++i) {
+        if (p[i] == 0.) continue;
+        const int d = ilogb(p[i]) - ek + 1, m = k - i;
+        const int q = d >= 0 ? (d + m - 1) / m : -((-d) / m);
+        if (q > emax) emax = q;
+    }
+    double R = emax == -100000 ? 1. : ldexp(1., emax + 1);
+    if (!(R < 1e12)) R = 1e12;
+    return R;
+}
+template <int K>
+__device__ __forceinline__ double root_bound_s(const double (&p)[11])
+{
+    const int ek = ilogb(p[K]);
+    int emax = -100000;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        if (p[i] != 0.) {
+            const int d = ilogb(p[i]) - ek + 1;
+            const int m = K - i;
+            const int q = d >= 0 ? (d + m - 1) / m : -((-d) / m);
+            if (q > emax) emax = q;
+        }
+    }
+    double R = emax == -100000 ? 1. : ldexp(1., emax + 1);
+    if (!(R < 1e12)) R = 1e12;
+    return R;
+}
+
 // generic path (degree < 10 after leading-coefficient trimming: rare): dynamic indexing
 __device__ static int poly_real_roots_generic(const double *c, int n, double *roots)
 {
@@ -88,10 +124,7 @@ __device__ static int poly_real_roots_generic(const double *c, int n, double *ro
         const double *crit = rts[cur];
         double *out = rts[cur ^ 1];
         int nout = 0;
-        double mx = 0.;
-        for (int i = 0; i < k; ++i) { double a = fabs(p[i]); if (a > mx) mx = a; }
-        double R = 1. + mx / fabs(p[k]);
-        if (!(R < 1e12)) R = 1e12;
+        double R = root_bound(p, k);
         for (int iv = 0; iv <= nr_prev; ++iv) {
             double a = (iv == 0) ? -R : crit[iv - 1];
             double b = (iv == nr_prev) ? R : crit[iv];
@@ -378,11 +411,7 @@ __device__ __forceinline__ int roots_level_grp(const double (&c)[11], double &cr
         for (int i = 0; i < kk; ++i) p[i] = p[i + 1] * (double)(i + 1);
 #pragma unroll
     for (int i = 0; i < K; ++i) dp[i] = p[i + 1] * (double)(i + 1);
-    double mx = 0.;
-#pragma unroll
-    for (int i = 0; i < K; ++i) { double a = fabs(p[i]); if (a > mx) mx = a; }
-    double R = 1. + mx / fabs(p[K]);
-    if (!(R < 1e12)) R = 1e12;
+    const double R = root_bound_s<K>(p);
     const double below = __shfl_up(crit, 1);
     double a = (j == 0) ? -R : below;
     double b = (j == nr_prev) ? R : crit;
