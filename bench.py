@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="split the batch over S engine handles (S HIP streams) so latency-bound stages overlap")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of the N>1 path)")
     ap.add_argument("--data-cache", default="", help="npz file to load/save the synthetic batch (keeps forks out of profiled runs)")
+    ap.add_argument("--unique", type=int, default=0, help="generate only this many distinct pairs and tile them to --batch "
+                    "(full-size config 3 runs: rendering 4096 HD pairs takes longer than measuring them)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -188,7 +190,12 @@ def main():
         i1, i2, Rgt, tgt = z["i1"], z["i2"], z["R"], z["t"]
         assert i1.shape == (B, H, W), "data cache does not match the requested workload"
     elif not args.stream:
-        i1, i2, Rgt, tgt = synthetic.make_batch(B, K, W, H, cfg=2, first=rank * B, workers=workers)
+        U = min(args.unique, B) if args.unique > 0 else B
+        i1, i2, Rgt, tgt = synthetic.make_batch(U, K, W, H, cfg=2, first=rank * B, workers=workers)
+        if U < B:
+            reps = -(-B // U)
+            i1, i2 = np.concatenate([i1] * reps)[:B], np.concatenate([i2] * reps)[:B]
+            Rgt, tgt = np.concatenate([Rgt] * reps)[:B], np.concatenate([tgt] * reps)[:B]
         if cache:
             np.savez(cache, i1=i1, i2=i2, R=Rgt, t=tgt)
 
@@ -317,7 +324,7 @@ def main():
                                     (f"; consecutive-frame stream of {B + 1} frames, features once per frame (configs[4] stand-in)" if args.stream else "")) if method == "ORB" else
                                    (f"{B} {W}x{H} pairs per GPU in sub-batches of {sub}, SIFT(cap {args.nfeatures})+BF-L2 crossCheck "
                                     f"top-{args.max_matches}+5pt-RANSAC+recoverPose (BASELINE configs[2]" + ("" if B >= 4096 else f" shape, {B} of its 4096 pairs") + ")"),
-                       "pairs_per_gpu": B, "global_pairs": world * B, "streams_per_gpu": S, "pairs_per_launch": Bl, "sharding": f"pairs x{world}, RCCL all-gather of 128-B pose records"},
+                       "pairs_per_gpu": B, "distinct_pairs": (min(args.unique, B) if args.unique > 0 else B), "global_pairs": world * B, "streams_per_gpu": S, "pairs_per_launch": Bl, "sharding": f"pairs x{world}, RCCL all-gather of 128-B pose records"},
             "median_rotation_error_deg": float(np.median(errs)) if len(errs) else None,
             "pairs_ok": int(ok.sum()),
             "stage_ms_per_launch": {k: round(v, 4) for k, v in stage_ms.items()},
