@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
     const int x0 = (ti % tcols) * PYR_TW, y0 = (ti / tcols) * 64;
     uint8_t *base = pyr + (long long)blockIdx.y * lay.stride;
     const uint8_t *src = base + S.off;
-    const int *xo = coef + D.coef_off, *xa = xo + D.w, *yo = xa + D.w, *ya = yo + D.h;
+    const int *cxp = coef + D.coef_off, *cyp = cxp + D.w;      // packed (offset | weight << 16) per column / row
     // conservative footprint: floor(scale*x0) <= xo[x0] (scale >= 1), checked on the host
     const int a0 = ((int)(((long long)x0 * S.w) / D.w)) & ~15;
     const int sy0 = (int)(((long long)y0 * S.h) / D.h);
@@ -99,10 +99,10 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
     }
     int o[4], a1[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { int x = min(x4 + j, D.w - 1); o[j] = xo[x]; a1[j] = xa[x]; }
+    for (int j = 0; j < 4; ++j) { const int cv = cxp[min(x4 + j, D.w - 1)]; o[j] = cv & 0xFFFF; a1[j] = cv >> 16; }
     int oy[8], b1[8];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) { int y = min(y0 + tyb + 8 * rr, D.h - 1); oy[rr] = yo[y]; b1[rr] = ya[y]; }
+    for (int rr = 0; rr < 8; ++rr) { const int cv = cyp[min(y0 + tyb + 8 * rr, D.h - 1)]; oy[rr] = cv & 0xFFFF; b1[rr] = cv >> 16; }
     __syncthreads();
     if (x4 >= D.pitch) return;
     const uint8_t *sb = (const uint8_t *)s_src;

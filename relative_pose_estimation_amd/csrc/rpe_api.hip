@@ -167,8 +167,21 @@ static int build_tables(rpe_handle *h)
             if (yo[y0] < s0 || hi - s0 >= 74) { h->err = "pyramid footprint bound violated (y)"; return RPE_ERR_INVALID; }
         }
     }
-    DM(h, h->d_coef, ncoef);
-    HIPCHK(h, hipMemcpy(h->d_coef, coef.data(), sizeof(int) * (size_t)ncoef, hipMemcpyHostToDevice));
+    // device form: (offset, weight) packed into one dword per destination column / row (offset < 65536, weight <= 256):
+    // the resize kernel fetches 12 table dwords per lane instead of 24.  Layout per level: [w packed x][h packed y]
+    // at coef_off (the unpacked host table keeps its 2(w+h) stride, so the offsets stay valid)
+    {
+        std::vector<int> packed((size_t)ncoef, 0);
+        for (int l = 1; l < RPE_NLEVELS; ++l) {
+            const RpeLevel &D = L.lv[l];
+            const int *xo = coef.data() + D.coef_off, *xa = xo + D.w, *yo = xa + D.w, *ya = yo + D.h;
+            int *px = packed.data() + D.coef_off, *py = px + D.w;
+            for (int x = 0; x < D.w; ++x) px[x] = xo[x] | (xa[x] << 16);
+            for (int y = 0; y < D.h; ++y) py[y] = yo[y] | (ya[y] << 16);
+        }
+        DM(h, h->d_coef, ncoef);
+        HIPCHK(h, hipMemcpy(h->d_coef, packed.data(), sizeof(int) * (size_t)ncoef, hipMemcpyHostToDevice));
+    }
     // intensity-centroid disc (orb.cpp umax table)
     {
         int umax[RPE_HALF_PATCH + 2];
