@@ -119,7 +119,10 @@ int rpe_synchronize(rpe_handle *h);
 /* replaces PoseEstimator.estimate (pose_estimator.py:487-533) for B pairs.
  * h_imgs1/h_imgs2: B images each (host).  Outputs (host, caller-allocated):
  * R[B*9], t[B*3], inliers[B] (= recoverPose return value, :621),
- * n_matches[B] (= len(matches), :627; may be NULL), status[B]. */
+ * n_matches[B] (= len(matches), :627; may be NULL), status[B].
+ * Large host batches (B >= 512 and >= 64 MiB per image set) are processed in four chunks whose uploads run on a
+ * copy stream behind the kernels of the previous chunk; results are identical, but the per-pair debug arrays
+ * (rpe_fetch_matched_points) then hold nothing usable and that call reports an error. */
 int rpe_estimate_batch(rpe_handle *h, const uint8_t *h_imgs1, const uint8_t *h_imgs2, int B,
                        const double K[9], double *R, double *t, int32_t *inliers,
                        int32_t *n_matches, int32_t *status);

@@ -62,6 +62,9 @@ struct rpe_handle {
     int desc_bytes = 32;                      // 32 (rBRIEF) or 128 (SIFT, stored as u8)
     std::string err;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;          // uploads of a chunked host batch (rpe_estimate_batch), created on first use
+    hipEvent_t ev_up[8] = {};                   // 'chunk c is resident' events
+    bool last_chunked = false;                  // the last host batch ran in chunks: per-pair debug arrays hold its last chunk only
     RpeDeviceLayout lay;
     int n_img_cap = 0;              // 2*max_batch
     // tile tables

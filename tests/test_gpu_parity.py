@@ -432,3 +432,24 @@ def test_sift_stream_equals_pairwise(capi, oracle):
     assert np.array_equal(Rs, Rp) and np.array_equal(ts, tp) and np.array_equal(inls, inlp) and np.array_equal(nms, nmp) and np.array_equal(sts, stp)
     assert sts[0] == 0
     e.close()
+
+
+def test_chunked_host_batch_equals_device_resident(capi, pairs, K_vga):
+    """rpe_estimate_batch on >= 512 host pairs overlaps the uploads of later chunks with the kernels of earlier ones;
+    results equal the one-piece device-resident run pair for pair"""
+    i1, i2, _, _ = pairs
+    B = 512
+    a = np.ascontiguousarray(np.concatenate([i1] * (B // len(i1) + 1))[:B]); b = np.ascontiguousarray(np.concatenate([i2] * (B // len(i2) + 1))[:B])
+    b[7] = 90                                                       # a failing pair inside a chunk
+    e = capi.Engine(640, 480, max_batch=B, nfeatures=1000)
+    host = e.estimate_batch(a, b, K_vga)
+    with pytest.raises(capi.RpeError, match="ran in chunks"):
+        e.fetch_matched_points(B)
+    da, db = e.upload(a), e.upload(b)
+    dev = e.estimate_batch_device(da, db, B, K_vga)
+    for x, y in zip(host, dev):
+        assert np.array_equal(x, y)
+    assert host[4][7] == capi.PAIR_NO_DESCRIPTORS and host[4][0] == 0
+    p1, p2 = e.fetch_matched_points(B)                               # available again after a device-resident batch
+    assert p1.shape == (B, 500, 2)
+    e.close()
