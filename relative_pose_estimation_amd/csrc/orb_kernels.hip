@@ -426,36 +426,39 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const uint8_t *_
             v[q] = make_uint4(0, 0, 0, 0);
             if (pos + 16 * q < nbytes) v[q] = *(const uint4 *)(src + pos + 16 * q);
         }
+        // byte >= tau for four bytes at a time (SWAR): with H = 0x80 per byte, ((x | H) - (T & ~H)) has bit 7 set where the
+        // low 7 bits compare >=, and the top bits decide otherwise; the flags stay at the byte MSBs, v_bcnt counts them
+        unsigned ge[16];
         int cnt = 0;
+        {
+            const unsigned H = 0x80808080u, T = (unsigned)tau * 0x01010101u, Tl = T & ~H, nT = ~T;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned wds[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-            if ((v[q].x | v[q].y | v[q].z | v[q].w) != 0) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) cnt += (int)((wds[k >> 2] >> (8 * (k & 3))) & 255) >= tau;
+            for (int d = 0; d < 16; ++d) {
+                const unsigned x = d < 4 ? (&v[0].x)[d] : d < 8 ? (&v[1].x)[d - 4] : d < 12 ? (&v[2].x)[d - 8] : (&v[3].x)[d - 12];
+                const unsigned lowge = (x | H) - Tl;
+                ge[d] = ((x & nT) | (~(x ^ T) & lowge)) & H;
+                cnt += __popc(ge[d]);
             }
         }
         int total;
         int ex = block_excl_scan(cnt, s_wave, total);
-        if (cnt) {
+        if (total) {                                               // block-uniform
             int o = base + ex;
             const int y0p = pos / L.pitch, x0p = pos - y0p * L.pitch;     // one division per lane, not one per byte
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const unsigned wds[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-                if ((v[q].x | v[q].y | v[q].z | v[q].w) == 0) continue;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    int b = (int)((wds[k >> 2] >> (8 * (k & 3))) & 255);
-                    if (b >= tau) {
-                        if (o < ccap) {
-                            int x = x0p + 16 * q + k, y = y0p;            // 64 bytes cross at most two row ends (pitch >= 48)
-                            if (x >= L.pitch) { x -= L.pitch; ++y; }
-                            if (x >= L.pitch) { x -= L.pitch; ++y; }
-                            out[o] = ((unsigned)(y + row0) << 16) | (unsigned)x;
-                        }
-                        ++o;
+            for (int d = 0; d < 16; ++d) {
+                if (__ballot(ge[d] != 0) == 0) continue;          // no lane of the wave has a hit in this dword (~half of them)
+                unsigned g = ge[d];
+                while (g) {
+                    const int k = 4 * d + ((__ffs((int)g) - 1) >> 3);      // byte index inside the 64
+                    g &= g - 1;
+                    if (o < ccap) {
+                        int x = x0p + k, y = y0p;                  // 64 bytes cross at most two row ends (pitch >= 48)
+                        if (x >= L.pitch) { x -= L.pitch; ++y; }
+                        if (x >= L.pitch) { x -= L.pitch; ++y; }
+                        out[o] = ((unsigned)(y + row0) << 16) | (unsigned)x;
                     }
+                    ++o;
                 }
             }
         }
