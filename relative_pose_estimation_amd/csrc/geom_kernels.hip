@@ -537,6 +537,39 @@ __global__ __launch_bounds__(256) void ransac_roots_kernel(const RpeRansacState 
 
 // ------------------------------------------------------- Sampson inlier test
 // EMEstimatorCallback::computeError + findInliers: (float)err <= (float)(thr*thr)
+// The same predicate without the f64 division (a ~30-instruction IEEE sequence in the innermost RANSAC loop).
+// (float)(num / den) <= thr2  <=>  fl64(num / den) <= B, B = the largest double that still rounds (to nearest even) to a
+// float <= thr2.  num <= 0.999.. * fl(B * den) proves the left side, num >= 1.000.. * fl(B * den) disproves it (margins
+// 2^-40, far above the 2^-53 rounding of the product and of the quotient); only the sliver in between (and den <= 0 /
+// non-finite values) takes the exact division.  Bit-identical to sampson_inlier by construction.
+struct SampsonBound { double B; };
+__device__ __forceinline__ SampsonBound sampson_bound(float thr2)
+{
+    const unsigned u = __float_as_uint(thr2);
+    const float nf = __uint_as_float(u + 1u);                             // next float above thr2 (thr2 > 0, finite)
+    const double m = 0.5 * ((double)thr2 + (double)nf);                   // exact midpoint: ties go to the even float
+    SampsonBound b;
+    b.B = (u & 1u) ? __longlong_as_double(__double_as_longlong(m) - 1) : m;
+    return b;
+}
+__device__ __forceinline__ int sampson_inlier_fast(const double *E, double x1, double y1, double x2, double y2, float thr2, SampsonBound sb)
+{
+    double Ex0 = (E[0] * x1 + E[1] * y1) + E[2];
+    double Ex1 = (E[3] * x1 + E[4] * y1) + E[5];
+    double Ex2 = (E[6] * x1 + E[7] * y1) + E[8];
+    double Et0 = (E[0] * x2 + E[3] * y2) + E[6];
+    double Et1 = (E[1] * x2 + E[4] * y2) + E[7];
+    double x2tEx1 = (x2 * Ex0 + y2 * Ex1) + Ex2;
+    double a = Ex0 * Ex0, b = Ex1 * Ex1, c = Et0 * Et0, d = Et1 * Et1;
+    const double num = x2tEx1 * x2tEx1, den = ((a + b) + c) + d;
+    const double p = sb.B * den;
+    if (den > 0. && p < 1e300) {
+        if (num <= p * (1. - 0x1p-40)) return 1;
+        if (num >= p * (1. + 0x1p-40)) return 0;
+    }
+    return (float)(num / den) <= thr2;
+}
+
 __device__ __forceinline__ int sampson_inlier(const double *E, double x1, double y1, double x2, double y2, float thr2)
 {
     double Ex0 = (E[0] * x1 + E[1] * y1) + E[2];
@@ -588,6 +621,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const double2 *__rest
     const double fx = K[0], fy = K[4];
     const double thr = threshold / ((fx + fy) / 2);
     const float thr2 = (float)(thr * thr);
+    const SampsonBound sbound = sampson_bound(thr2);
     const int total = s_first[64];
     int k = 0;
     for (int j = wv; j < total; j += 4) {            // j-th model of this group, flattened (iteration-major)
@@ -600,7 +634,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const double2 *__rest
         int cnt = 0;
         for (int i = lane; i < M; i += 64) {
             double2 a = sp1[i], b = sp2[i];
-            cnt += sampson_inlier(E, a.x, a.y, b.x, b.y, thr2);
+            cnt += sampson_inlier_fast(E, a.x, a.y, b.x, b.y, thr2, sbound);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
