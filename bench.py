@@ -289,6 +289,8 @@ def main():
     R, t, inl, nm, st = local
     ok = st == 0
     errs = np.array([geometry.rotation_error(R[i], Rgt[i]) for i in range(B) if ok[i]])
+    # translation is recovered up to scale: direction error against the ground-truth direction (pose_evaluator.py:111-116)
+    terrs = np.array([geometry.translation_direction_error(t[i], tgt[i]) for i in range(B) if ok[i] and np.linalg.norm(tgt[i]) > 0])
     # per-LAUNCH averages: every step launches each kernel group once per stream on B/S pairs
     stage_ms = {k: v / (args.steps * S) for k, v in stage_acc.items()}
     Bl = B // S if B % S == 0 else B / S          # pairs per launch
@@ -326,6 +328,7 @@ def main():
                                     f"top-{args.max_matches}+5pt-RANSAC+recoverPose (BASELINE configs[2]" + ("" if B >= 4096 else f" shape, {B} of its 4096 pairs") + ")"),
                        "pairs_per_gpu": B, "distinct_pairs": (min(args.unique, B) if args.unique > 0 else B), "global_pairs": world * B, "streams_per_gpu": S, "pairs_per_launch": Bl, "sharding": f"pairs x{world}, RCCL all-gather of 128-B pose records"},
             "median_rotation_error_deg": float(np.median(errs)) if len(errs) else None,
+            "median_translation_dir_error_deg": float(np.median(terrs)) if len(terrs) else None,
             "pairs_ok": int(ok.sum()),
             "stage_ms_per_launch": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"kernel": names.get(dom, dom), "stage": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
