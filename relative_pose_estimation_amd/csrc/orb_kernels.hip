@@ -479,14 +479,19 @@ __global__ __launch_bounds__(256) void harris_kernel(const uint8_t *__restrict__
                                                       const int *__restrict__ cand_count, float *__restrict__ cand_resp,
                                                       RpeDeviceLayout lay)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
-    if (c >= lay.cand_total) return;
-    int l = 0;
+    // dense lane -> candidate mapping over the per-level counts: the slot arrays are sized 4*quota + 256 per level but
+    // hold ~2*quota entries, so slot-indexed lanes were two thirds idle
+    const int dsel = blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
+    int l = -1, ci = 0, acc = 0;
 #pragma unroll
-    for (int k = 1; k < RPE_NLEVELS; ++k) if (c >= lay.lv[k].cand_off) l = k;
+    for (int k = 0; k < RPE_NLEVELS; ++k) {
+        const int n = cand_count[img * RPE_NLEVELS + k];
+        if (l < 0 && dsel < acc + n) { l = k; ci = dsel - acc; }
+        acc += n;
+    }
+    if (l < 0) return;
     const RpeLevel &L = lay.lv[l];
-    const int ci = c - L.cand_off;
-    if (ci >= cand_count[img * RPE_NLEVELS + l]) return;
+    const int c = L.cand_off + ci;
     unsigned xy = cand_xy[(long long)img * lay.cand_total + c];
     const int x0 = xy & 0xFFFF, y0 = xy >> 16, pitch = L.pitch;
     const uint8_t *p0 = pyr + (long long)img * lay.stride + L.off + (long long)(y0 - 4) * pitch + (x0 - 4);
