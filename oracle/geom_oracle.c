@@ -26,6 +26,11 @@
 #include <stdlib.h>
 
 /* ------------------------------------------------------------------ RNG */
+/* Experiment knob (tools/reference_rows.py, tests): the RANSAC seed.  cv2 always uses (uint64)-1; other
+ * values exist only to measure how far one pair's pose moves with the sample stream. */
+static uint64_t g_ransac_seed = 0xFFFFFFFFFFFFFFFFULL;
+void orc_debug_set_ransac_seed(uint64_t seed) { g_ransac_seed = seed; }
+
 /* cv::RNG::next(): state = (uint32)state * 4164903690 + (state >> 32) */
 uint32_t orc_rng_next(uint64_t *state)
 {
@@ -413,7 +418,7 @@ int orc_find_essential(const float *pts1, const float *pts2, int M, const double
         }
     } else {
         int niters = max_iters, best = 0;
-        uint64_t st = 0xFFFFFFFFFFFFFFFFULL;
+        uint64_t st = g_ransac_seed;
         uint8_t *cur = (uint8_t *)malloc((size_t)M);
         int iter;
         for (iter = 0; iter < niters; ++iter) {
@@ -583,4 +588,42 @@ int orc_recover_pose(const double *E, const float *pts1, const float *pts2, int 
     memcpy(R, Rs, sizeof(double) * 9);
     memcpy(t, ts, sizeof(double) * 3);
     return g;
+}
+
+/* ------------------------------------------------ pose from matched points, batched */
+/* findEssentialMat + recoverPose (pose_estimator.py:522-533) on already matched points, one thread per
+ * slice of the batch: lets tests replay the geometry stage of many pairs under several RANSAC seeds
+ * (orc_debug_set_ransac_seed) without re-extracting features.  pts: B x 2 x mm x 2 f32 as written by
+ * orc_estimate_pose_batch_pts; nm[b] = matches of pair b. */
+#include <pthread.h>
+typedef struct { const float *pts; const int32_t *nm; int B, mm; const double *K; orc_pose_result *out; int tid, nt; } pjob_t;
+static void *pose_worker(void *arg)
+{
+    pjob_t *j = (pjob_t *)arg;
+    for (int b = j->tid; b < j->B; b += j->nt) {
+        orc_pose_result *o = &j->out[b];
+        const float *p1 = j->pts + 4 * (size_t)j->mm * b, *p2 = p1 + 2 * (size_t)j->mm;
+        const int M = j->nm[b];
+        memset(o, 0, sizeof(*o));
+        o->n_matches = M;
+        if (M < 5) { o->status = ORC_INSUFFICIENT_MATCHES; continue; }
+        double E[9];
+        if (!orc_find_essential(p1, p2, M, j->K, 0.999, 1.0, 1000, E, NULL, NULL)) { o->status = ORC_NO_ESSENTIAL; continue; }
+        o->inliers = orc_recover_pose(E, p1, p2, M, j->K, o->R, o->t);
+        o->status = ORC_OK;
+    }
+    return NULL;
+}
+void orc_pose_from_points_batch(const float *pts, const int32_t *nm, int B, int mm, const double *K,
+                                orc_pose_result *out, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    pthread_t th[64]; pjob_t jb[64];
+    for (int t = 0; t < nthreads; ++t) {
+        pjob_t j = {pts, nm, B, mm, K, out, t, nthreads};
+        jb[t] = j;
+        pthread_create(&th[t], NULL, pose_worker, &jb[t]);
+    }
+    for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
 }

@@ -206,15 +206,39 @@ def estimate_pose(img1, img2, K, nfeatures=4000, max_matches=500):
             "inliers": res.inliers, "R": np.array(res.R).reshape(3, 3), "t": np.array(res.t).reshape(3, 1)}
 
 
-def estimate_pose_batch(imgs1, imgs2, K, nfeatures=4000, max_matches=500, nthreads=1, method="ORB"):
+def set_ransac_seed(seed=0xFFFFFFFFFFFFFFFF):
+    """Experiment knob: cv2's RANSAC seed is always (uint64)-1 (the default)."""
+    lib().orc_debug_set_ransac_seed(C.c_uint64(seed))
+
+
+def set_variant(key, val):
+    lib().orc_debug_set_variant(int(key), int(val))
+
+
+def estimate_pose_batch(imgs1, imgs2, K, nfeatures=4000, max_matches=500, nthreads=1, method="ORB", return_points=False):
     imgs1 = np.ascontiguousarray(imgs1, np.uint8); imgs2 = np.ascontiguousarray(imgs2, np.uint8)
     K = np.ascontiguousarray(K, np.float64)
     B, H, W = imgs1.shape
     out = np.zeros(B, POSE_DTYPE)
+    if return_points:
+        assert method.upper() == "ORB" and max_matches > 0
+        pts = np.zeros((B, 2, max_matches, 2), np.float32)
+        lib().orc_estimate_pose_batch_pts(_p(imgs1), _p(imgs2), B, W, H, _p(K), nfeatures, max_matches, _p(out), nthreads, _p(pts))
+        return out, pts
     if method.upper() == "SIFT":
         lib().orc_estimate_pose_sift_batch(_p(imgs1), _p(imgs2), B, W, H, _p(K), nfeatures, max_matches, _p(out), nthreads)
         return out
     lib().orc_estimate_pose_batch(_p(imgs1), _p(imgs2), B, W, H, _p(K), nfeatures, max_matches, _p(out), nthreads)
+    return out
+
+
+def pose_from_points_batch(pts, n_matches, K, nthreads=1):
+    """findEssentialMat + recoverPose on the matched points returned by estimate_pose_batch(return_points=True)."""
+    pts = np.ascontiguousarray(pts, np.float32); nm = np.ascontiguousarray(n_matches, np.int32)
+    K = np.ascontiguousarray(K, np.float64)
+    B, _, mm, _ = pts.shape
+    out = np.zeros(B, POSE_DTYPE)
+    lib().orc_pose_from_points_batch(_p(pts), _p(nm), B, mm, _p(K), _p(out), nthreads)
     return out
 
 

@@ -34,6 +34,14 @@
 
 static int cv_round(double v) { return (int)lrint(v); }
 
+/* Experiment knobs (tools/reference_rows.py): conventions cv2 leaves implementation-defined or that this
+ * restatement had to guess.  Key 0: Gaussian taps (0 = [18,34,49,55,...] = cvRound(256 g_i), sum 257, the
+ * sepFilter2D fixed-point route ORB's in-place blur of a pyramid sub-matrix takes; 1 = [18,34,48,56,...],
+ * the sum-256 set of round 1).  Key 1: keypoint order inside a level (0 = raster; 1 = Harris response
+ * descending, raster on ties; 2 = reverse raster).  Defaults are what the HIP path implements. */
+static int g_variant[4] = {0, 0, 0, 0};
+void orc_debug_set_variant(int key, int val) { if (key >= 0 && key < 4) g_variant[key] = val; }
+
 /* orb.cpp: layer scale (float)pow(scaleFactor, level), size cvRound(cols/scale);
  * per-level feature quota (geometric series, remainder to the last level). */
 void orc_orb_layout_init(int W, int H, int nfeatures, orc_orb_layout *L)
@@ -43,8 +51,9 @@ void orc_orb_layout_init(int W, int H, int nfeatures, orc_orb_layout *L)
     for (int l = 0; l < NLEVELS; ++l) {
         float s = (float)pow(sf, (double)l);
         L->scale[l] = s;
-        L->w[l] = cv_round((double)((float)W / s));
-        L->h[l] = cv_round((double)((float)H / s));
+        const float inv_scale = 1.0f / s;                        /* orb.cpp: Size sz(cvRound(image.cols * inv_scale), ...) */
+        L->w[l] = cv_round((double)((float)W * inv_scale));
+        L->h[l] = cv_round((double)((float)H * inv_scale));
         L->offset[l] = off;
         off += (int64_t)L->w[l] * L->h[l];
     }
@@ -154,11 +163,12 @@ void orc_orb_nms_map(const uint8_t *score, int w, int h, uint8_t *nms)
 }
 
 /* fixed-point separable Gaussian 7x7 sigma 2, BORDER_REFLECT_101 */
-static const int GK[7] = {18, 34, 48, 56, 48, 34, 18};
+static const int GK_TAB[2][7] = {{18, 34, 49, 55, 49, 34, 18}, {18, 34, 48, 56, 48, 34, 18}};
 static int refl(int p, int n) { if (p < 0) p = -p; if (p >= n) p = 2 * n - 2 - p; return p; }
 
 void orc_orb_blur_level(const uint8_t *src, int w, int h, uint8_t *dst)
 {
+    const int *GK = GK_TAB[g_variant[0] & 1];
     uint16_t *tmp = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)w * h);
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
@@ -170,7 +180,8 @@ void orc_orb_blur_level(const uint8_t *src, int w, int h, uint8_t *dst)
         for (int x = 0; x < w; ++x) {
             uint32_t s = 0;
             for (int k = 0; k < 7; ++k) s += (uint32_t)GK[k] * tmp[(size_t)refl(y + k - 3, h) * w + x];
-            dst[(size_t)y * w + x] = (uint8_t)((s + 32768u) >> 16);
+            s = (s + 32768u) >> 16;
+            dst[(size_t)y * w + x] = (uint8_t)(s > 255u ? 255u : s);     /* FixedPtCastEx saturates */
         }
     free(tmp);
 }
@@ -337,14 +348,27 @@ int orc_orb_detect_and_compute(const uint8_t *img, int W, int H, int nfeatures,
             th = kth_largest_f(r, nc, q);
             free(r);
         }
-        for (int i = 0; i < nc && nk < cap; ++i) {
-            if (!(cd[i].resp >= th)) continue;
+        /* experiment knob 1: emission order inside the level (default raster) */
+        int *ord = (int *)malloc(sizeof(int) * (size_t)(nc + 1)), no = 0;
+        for (int i = 0; i < nc; ++i) if (cd[i].resp >= th) ord[no++] = i;
+        if (g_variant[1] == 1) {
+            for (int a = 1; a < no; ++a) {           /* stable insertion sort, response descending */
+                int v = ord[a], b = a - 1;
+                while (b >= 0 && cd[ord[b]].resp < cd[v].resp) { ord[b + 1] = ord[b]; --b; }
+                ord[b + 1] = v;
+            }
+        } else if (g_variant[1] == 2) {
+            for (int a = 0; a < no / 2; ++a) { int t = ord[a]; ord[a] = ord[no - 1 - a]; ord[no - 1 - a] = t; }
+        }
+        for (int oi = 0; oi < no && nk < cap; ++oi) {
+            const int i = ord[oi];
             orc_keypoint *k = &kps[nk++];
             k->lx = cd[i].x; k->ly = cd[i].y; k->octave = l; k->response = cd[i].resp;
             k->angle = ic_angle(lv, w, cd[i].x, cd[i].y);
             k->x = (float)cd[i].x * L.scale[l];
             k->y = (float)cd[i].y * L.scale[l];
         }
+        free(ord);
         free(cd);
     }
     /* descriptors on the blurred pyramid (orb.cpp computeOrbDescriptors, WTA_K = 2) */
@@ -381,9 +405,12 @@ int orc_orb_detect_and_compute(const uint8_t *img, int W, int H, int nfeatures,
 }
 
 /* ---------------------------------------------------------- end to end */
-int orc_estimate_pose(const uint8_t *img1, const uint8_t *img2, int W, int H,
-                      const double *K, int nfeatures, int max_matches,
-                      orc_pose_result *out)
+/* pts_out (optional): the matched points handed to findEssentialMat, 2 x max_matches x 2 f32
+ * (pts1 then pts2) -- lets a test replay RANSAC + recoverPose with other seeds without
+ * re-extracting features. */
+static int estimate_pose_ex(const uint8_t *img1, const uint8_t *img2, int W, int H,
+                            const double *K, int nfeatures, int max_matches,
+                            orc_pose_result *out, float *pts_out)
 {
     memset(out, 0, sizeof(*out));
     int cap = nfeatures + 64;
@@ -403,6 +430,10 @@ int orc_estimate_pose(const uint8_t *img1, const uint8_t *img2, int W, int H,
         p1[2 * i] = k1[qi[i]].x; p1[2 * i + 1] = k1[qi[i]].y;
         p2[2 * i] = k2[ti[i]].x; p2[2 * i + 1] = k2[ti[i]].y;
     }
+    if (pts_out && max_matches >= 0) {
+        memcpy(pts_out, p1, sizeof(float) * 2 * (size_t)M);
+        memcpy(pts_out + 2 * (size_t)max_matches, p2, sizeof(float) * 2 * (size_t)M);
+    }
     double E[9];
     if (!orc_find_essential(p1, p2, M, K, 0.999, 1.0, 1000, E, NULL, NULL)) { out->status = ORC_NO_ESSENTIAL; goto done; }
     out->inliers = orc_recover_pose(E, p1, p2, M, K, out->R, out->t);
@@ -412,27 +443,45 @@ done:
     return out->status;
 }
 
+int orc_estimate_pose(const uint8_t *img1, const uint8_t *img2, int W, int H,
+                      const double *K, int nfeatures, int max_matches,
+                      orc_pose_result *out)
+{
+    return estimate_pose_ex(img1, img2, W, H, K, nfeatures, max_matches, out, NULL);
+}
+
 #include <pthread.h>
 typedef struct {
-    const uint8_t *i1, *i2; int B, W, H; const double *K; int nf, mm; orc_pose_result *out; int tid, nt;
+    const uint8_t *i1, *i2; int B, W, H; const double *K; int nf, mm; orc_pose_result *out; int tid, nt; float *pts;
 } job_t;
 static void *worker(void *arg)
 {
     job_t *j = (job_t *)arg;
     size_t sz = (size_t)j->W * j->H;
     for (int b = j->tid; b < j->B; b += j->nt)
-        orc_estimate_pose(j->i1 + sz * b, j->i2 + sz * b, j->W, j->H, j->K, j->nf, j->mm, &j->out[b]);
+        estimate_pose_ex(j->i1 + sz * b, j->i2 + sz * b, j->W, j->H, j->K, j->nf, j->mm, &j->out[b],
+                         j->pts ? j->pts + 4 * (size_t)j->mm * b : NULL);
     return NULL;
 }
+void orc_estimate_pose_batch_pts(const uint8_t *imgs1, const uint8_t *imgs2, int B, int W, int H,
+                                 const double *K, int nfeatures, int max_matches,
+                                 orc_pose_result *out, int nthreads, float *pts);
 void orc_estimate_pose_batch(const uint8_t *imgs1, const uint8_t *imgs2, int B, int W, int H,
                              const double *K, int nfeatures, int max_matches,
                              orc_pose_result *out, int nthreads)
+{
+    orc_estimate_pose_batch_pts(imgs1, imgs2, B, W, H, K, nfeatures, max_matches, out, nthreads, NULL);
+}
+/* pts (optional): B x 2 x max_matches x 2 f32, see estimate_pose_ex */
+void orc_estimate_pose_batch_pts(const uint8_t *imgs1, const uint8_t *imgs2, int B, int W, int H,
+                                 const double *K, int nfeatures, int max_matches,
+                                 orc_pose_result *out, int nthreads, float *pts)
 {
     if (nthreads < 1) nthreads = 1;
     pthread_t th[256]; job_t jb[256];
     if (nthreads > 256) nthreads = 256;
     for (int t = 0; t < nthreads; ++t) {
-        job_t j = {imgs1, imgs2, B, W, H, K, nfeatures, max_matches, out, t, nthreads};
+        job_t j = {imgs1, imgs2, B, W, H, K, nfeatures, max_matches, out, t, nthreads, pts};
         jb[t] = j;
         pthread_create(&th[t], NULL, worker, &jb[t]);
     }

@@ -681,7 +681,6 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
     float a = 1.f, b = 0.f;
     if (active) {
         // ---- orb.cpp ICAngles: integer moments over the disc, reduced with wave shuffles
-        const uint8_t *rb = (const uint8_t *)raw + KP_R * (KP_RAW_DW * 4) + off0 + KP_R;   // centre pixel
         // integer sums, so any summation order gives the oracle's moments: 4 disc pixels per packed-u8 dot product
         int m10 = 0, m01 = 0;
         {
@@ -721,8 +720,9 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
             const unsigned w0 = rw[d0], w1 = rw[d0 + 1], w2 = rw[min(d0 + 2, KP_RAW_DW - 1)], w3 = rw[min(d0 + 3, KP_RAW_DW - 1)];
             const unsigned q0 = __builtin_amdgcn_alignbyte(w1, w0, sh), q1 = __builtin_amdgcn_alignbyte(w2, w1, sh),
                            q2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
-            // taps [18,34,48,56 | 48,34,18,0] as two packed-u8 dot products per output (v_dot4_u32_u8)
-            const unsigned W0 = 18u | (34u << 8) | (48u << 16) | (56u << 24), W1 = 48u | (34u << 8) | (18u << 16);
+            // taps [18,34,49,55 | 49,34,18,0] = cvRound(256 g_i) (sum 257: a row sum still fits 16 bits, 255 * 257 = 65535)
+            // as two packed-u8 dot products per output (v_dot4_u32_u8)
+            const unsigned W0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), W1 = 49u | (34u << 8) | (18u << 16);
             unsigned o[4];
             o[0] = __builtin_amdgcn_udot4(q1, W1, __builtin_amdgcn_udot4(q0, W0, 0u, false), false);
             o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(q2, q1, 1), W1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(q1, q0, 1), W0, 0u, false), false);
@@ -752,9 +752,9 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const unsigned short *col = hs + (iys[e] + dyo) * (KP_H_DW * 2) + ixs[e] + dxo;
-            unsigned s = 18u * col[0] + 34u * col[KP_H_DW * 2] + 48u * col[2 * KP_H_DW * 2] + 56u * col[3 * KP_H_DW * 2] +
-                         48u * col[4 * KP_H_DW * 2] + 34u * col[5 * KP_H_DW * 2] + 18u * col[6 * KP_H_DW * 2];
-            t01[e] = (int)((s + 32768u) >> 16);
+            unsigned s = 18u * col[0] + 34u * col[KP_H_DW * 2] + 49u * col[2 * KP_H_DW * 2] + 55u * col[3 * KP_H_DW * 2] +
+                         49u * col[4 * KP_H_DW * 2] + 34u * col[5 * KP_H_DW * 2] + 18u * col[6 * KP_H_DW * 2];
+            t01[e] = (int)min((s + 32768u) >> 16, 255u);              // FixedPtCastEx<int, uchar> saturates (taps sum to 257)
         }
         nib |= (unsigned)(t01[0] < t01[1]) << bit;
     }
@@ -771,8 +771,9 @@ void rpe_launch_angle(rpe_handle *h, int n_img)
 }
 
 // ------------------------------------------------------------------- blur
-// GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101), 8.8 fixed-point separable
-// kernel [18,34,48,56,48,34,18]; result (sum + 2^15) >> 16.
+// GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) as ORB runs it (in place on a pyramid sub-matrix => cv2's
+// sepFilter2D route): separable integer kernel cvRound(256 g_i) = [18,34,49,55,49,34,18] (sum 257);
+// result saturate_u8((sum + 2^15) >> 16).
 __device__ __forceinline__ int refl101(int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * n - 2 - p : p; }
 
 __global__ __launch_bounds__(256) void blur_kernel(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ dst,
@@ -818,12 +819,12 @@ __global__ __launch_bounds__(256) void blur_kernel(const uint8_t *__restrict__ p
         unsigned o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            o[j] = 18u * p[j + 1] + 34u * p[j + 2] + 48u * p[j + 3] + 56u * p[j + 4] + 48u * p[j + 5] + 34u * p[j + 6] + 18u * p[j + 7];
+            o[j] = 18u * p[j + 1] + 34u * p[j + 2] + 49u * p[j + 3] + 55u * p[j + 4] + 49u * p[j + 5] + 34u * p[j + 6] + 18u * p[j + 7];
         s_h[i] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
     }
     __syncthreads();
     const int tx = tid & 15, tyb = tid >> 4;
-    const unsigned kk[7] = {18u, 34u, 48u, 56u, 48u, 34u, 18u};
+    const unsigned kk[7] = {18u, 34u, 49u, 55u, 49u, 34u, 18u};
 #pragma unroll
     for (int rr = 0; rr < TH / 16; ++rr) {
         const int ty = tyb + 16 * rr;
@@ -834,8 +835,8 @@ __global__ __launch_bounds__(256) void blur_kernel(const uint8_t *__restrict__ p
             acc[0] += kk[r] * (v.x & 0xFFFF); acc[1] += kk[r] * (v.x >> 16);
             acc[2] += kk[r] * (v.y & 0xFFFF); acc[3] += kk[r] * (v.y >> 16);
         }
-        unsigned out = ((acc[0] + 32768u) >> 16) | (((acc[1] + 32768u) >> 16) << 8) | (((acc[2] + 32768u) >> 16) << 16) |
-                       (((acc[3] + 32768u) >> 16) << 24);
+        unsigned out = min((acc[0] + 32768u) >> 16, 255u) | (min((acc[1] + 32768u) >> 16, 255u) << 8) |
+                       (min((acc[2] + 32768u) >> 16, 255u) << 16) | (min((acc[3] + 32768u) >> 16, 255u) << 24);
         int px = x0 + 4 * tx, py = y0 + ty;
         if (py < hgt && px < pitch) *(unsigned *)(dst + ibase + (long long)py * pitch + px) = out;
     }

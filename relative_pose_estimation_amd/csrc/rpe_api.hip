@@ -65,8 +65,9 @@ static void build_layout(rpe_handle *h)
     for (int l = 0; l < RPE_NLEVELS; ++l) {
         RpeLevel &v = L.lv[l];
         v.scale = (float)pow(sf, (double)l);
-        v.w = cv_round((double)((float)W / v.scale));
-        v.h = cv_round((double)((float)H / v.scale));
+        const float inv_scale = 1.0f / v.scale;                  // orb.cpp: Size sz(cvRound(image.cols * inv_scale), ...)
+        v.w = cv_round((double)((float)W * inv_scale));
+        v.h = cv_round((double)((float)H * inv_scale));
         v.pitch = (int)align_up(v.w, 16);
         v.off = off;
         off = align_up(off + (long long)v.pitch * v.h, 256);

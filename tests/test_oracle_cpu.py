@@ -169,31 +169,18 @@ def test_orb_properties(oracle, K_vga):
     assert np.all((kps["angle"] >= 0) & (kps["angle"] <= 360))
     k2, d2 = oracle.orb_detect_and_compute(img, 1000)
     assert np.array_equal(desc, d2)
-    # blur: constant image stays constant (kernel sums to 256), impulse response = outer(k, k)/2^16
-    assert np.all(oracle.blur_level(np.full((40, 50), 93, np.uint8)) == 93)
+    # blur: taps cvRound(256 g_i) = [18,34,49,55,49,34,18] sum to 257 (cv2's sepFilter2D fixed-point route does not
+    # renormalise): a constant c becomes (c * 257^2 + 2^15) >> 16, saturated; impulse response = outer(k, k) / 2^16
+    assert np.all(oracle.blur_level(np.full((40, 50), 93, np.uint8)) == (93 * 257 * 257 + 32768) >> 16)
+    assert np.all(oracle.blur_level(np.full((40, 50), 255, np.uint8)) == 255)
     imp = np.zeros((21, 21), np.uint8); imp[10, 10] = 255
-    k = np.array([18, 34, 48, 56, 48, 34, 18])
+    k = np.array([18, 34, 49, 55, 49, 34, 18])
     assert np.array_equal(oracle.blur_level(imp)[7:14, 7:14], (np.outer(k, k) * 255 + 32768) >> 16)
     assert abs(oracle.fast_atan2(1.0, 1.0) - 45) < 0.02 and abs(oracle.fast_atan2(-1.0, 0.0) - 270) < 0.02
 
 
-def test_forward_known_answers(oracle):
-    """Reference's committed result rows (evaluation_results.csv) for committed image
-    pairs: statistical agreement (stage-level parity with cv2 is unpinned)."""
-    from relative_pose_estimation_amd import geometry as g
-    z = np.load(os.path.join(GOLD, "forward_pairs.npz"))
-    conv = str(z["convention"])
-    for i in range(len(z["frames"])):
-        r = oracle.estimate_pose(z["img1"][i], z["img2"][i], z["K"], 4000, 500)   # pipeline.py:94-101 parameters
-        assert r["status"] == 0 and r["n_matches"] == 500
-        g1, g2 = z["gt1"][i], z["gt2"][i]
-        R_prev = g.euler_to_rotation(g1[5], g1[4], g1[3], conv)                    # batch_processor.py:82-89
-        R_new = R_prev @ r["R"]                                                    # batch_processor.py:97
-        err = g.rotation_error(R_new, g.euler_to_rotation(g2[5], g2[4], g2[3], conv))
-        assert err <= z["ref_rot_err"][i] + 0.5, (z["frames"][i], err, z["ref_rot_err"][i])
-        yaw, pitch, roll = g.rotation_to_euler(R_new, conv)
-        ref_roll, ref_pitch, ref_yaw = z["ref_est"][i]
-        assert abs(yaw - ref_yaw) < 1.5 and abs(pitch - ref_pitch) < 1.5 and abs(roll - ref_roll) < 1.5
+# The oracle against the reference's own answers (all 147 committed result rows, with the measured RANSAC-seed
+# spread) lives in tests/test_reference_rows_cpu.py.
 
 
 def test_sift_oracle_properties(oracle):
