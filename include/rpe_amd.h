@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RPE_ABI_VERSION 1
+#define RPE_ABI_VERSION 2
 #define RPE_ORB_LEVELS 12
 
 /* per-pair status codes (status[] outputs) */
@@ -45,7 +45,23 @@ enum {
     RPE_PAIR_OK = 0,
     RPE_PAIR_NO_DESCRIPTORS = 1,       /* pose_estimator.py:508-509 */
     RPE_PAIR_INSUFFICIENT_MATCHES = 2, /* pose_estimator.py:514-515 */
-    RPE_PAIR_NO_ESSENTIAL = 3          /* pose_estimator.py:529-530 */
+    RPE_PAIR_NO_ESSENTIAL = 3,         /* pose_estimator.py:529-530 */
+    /* exactly 5 matches and the five-point solver returned more than one model: cv2.findEssentialMat then
+     * returns all of them stacked (3n x 3, ptsetreg.cpp count == modelPoints) and the reference's
+     * cv2.recoverPose(E, ...) call (pose_estimator.py:533) fails its `E.cols == 3 && E.rows == 3` assertion */
+    RPE_PAIR_AMBIGUOUS_ESSENTIAL = 4
+};
+
+/* Capacity flags of the last batch (rpe_fetch_overflow): a fixed-size workspace truncated a list that cv2
+ * would have kept whole, so the pair's features differ from the reference's although status is RPE_PAIR_OK. */
+enum {
+    RPE_OVF_ORB_CANDIDATES = 1 << 0,   /* a pyramid level had more than 4*quota+256 FAST candidates at the retainBest(2*quota) score */
+    RPE_OVF_ORB_KEYPOINTS  = 1 << 1,   /* more than nfeatures+64 keypoints after the Harris retainBest (ties) */
+    RPE_OVF_SIFT_SEEDS     = 1 << 4,   /* more scale-space extrema than base_pixels/16 */
+    RPE_OVF_SIFT_RAW       = 1 << 5,   /* more oriented keypoints than the raw list holds */
+    RPE_OVF_SIFT_PREFILTER = 1 << 6,   /* response ties overflowed the pre-sort window */
+    RPE_OVF_SIFT_CAP       = 1 << 7,   /* the nfeatures cap removed keypoints: differs from the reference's uncapped SIFT_create() (pose_estimator.py:93-94) */
+    RPE_OVF_SIFT_KEYPOINTS = 1 << 8    /* more than nfeatures+64 keypoints after retainBest (ties) */
 };
 
 /* library error codes (function return values) */
@@ -58,6 +74,10 @@ enum {
 
 enum { RPE_FEATURE_ORB = 0, RPE_FEATURE_SIFT = 1 };
 enum { RPE_NORM_HAMMING = 0, RPE_NORM_L2 = 1 };
+/* RPE_MATCH_CROSSCHECK = the reference (BFMatcher(norm, crossCheck=True).match, pose_estimator.py:131,144).
+ * RPE_MATCH_RATIO = opt-in extension named by the project brief, NOT in the reference: knnMatch(k=2) + Lowe's
+ * ratio test (best < ratio * second best), no cross check; then the same sort / top-max_matches. */
+enum { RPE_MATCH_CROSSCHECK = 0, RPE_MATCH_RATIO = 1 };
 
 /* Mirrors PoseEstimator.__init__ kwargs (pose_estimator.py:19-32) plus the
  * constants hard-coded at the reference's cv2 call sites. */
@@ -68,12 +88,15 @@ typedef struct rpe_config {
     int32_t max_batch;        /* max pairs per call */
     int32_t feature_method;   /* RPE_FEATURE_ORB        (pose_estimator.py:22) */
     int32_t norm_type;        /* RPE_NORM_HAMMING       (pose_estimator.py:23) */
-    int32_t max_matches;      /* default 500            (pose_estimator.py:24) */
+    int32_t max_matches;      /* default 500            (pose_estimator.py:24); 5 .. nfeatures+64 (= keypoint capacity: "no truncation", :150-151) */
     int32_t nfeatures;        /* default 4000           (pose_estimator.py:25) */
     int32_t fast_threshold;   /* 15                     (pose_estimator.py:89) */
     int32_t ransac_max_iters; /* 1000 (cv2 default maxIters) */
     double  ransac_prob;      /* 0.999                  (pose_estimator.py:525) */
     double  ransac_threshold; /* 1.0 px                 (pose_estimator.py:526) */
+    int32_t match_mode;       /* RPE_MATCH_CROSSCHECK   (pose_estimator.py:131) */
+    int32_t reserved0;
+    double  match_ratio;      /* Lowe ratio for RPE_MATCH_RATIO (default 0.75; unused by the reference mode) */
 } rpe_config;
 
 typedef struct rpe_handle rpe_handle;
@@ -136,6 +159,8 @@ int rpe_enqueue_batch_device(rpe_handle *h, const uint8_t *d_imgs1, const uint8_
                              const double K[9]);
 int rpe_fetch_results(rpe_handle *h, int B, double *R, double *t, int32_t *inliers,
                       int32_t *n_matches, int32_t *status);
+/* RPE_OVF_* flags of the last batch / stream, one word per pair (the OR of its two images' flags) */
+int rpe_fetch_overflow(rpe_handle *h, int n_pairs, uint32_t *flags);
 /* Consecutive-frame stream = the pair loop of BatchProcessor.process_sequence (reference
  * src/core/batch_processor.py:71-109): F frames -> F-1 relative poses (frame i -> i+1), features
  * extracted once per frame.  F <= 2*max_batch, F-1 <= max_batch.  Outputs sized F-1. */
@@ -170,9 +195,11 @@ int rpe_fetch_matched_points(rpe_handle *h, int B, float *pts1, float *pts2);
  * desc[n_images*cap*32], counts[n_images]; cap = rpe_keypoint_capacity(). */
 int rpe_orb_detect_and_compute(rpe_handle *h, const uint8_t *h_imgs, int n_images,
                                rpe_keypoint *kps, uint8_t *desc, int32_t *counts);
-/* intermediate images of image `index` of the last ORB run, in the ORACLE's
+/* intermediate images of image `index` of the last rpe_orb_detect_and_compute run, in the ORACLE's
  * packed pyramid layout (levels back to back, total = sum w_l*h_l):
- * which = 0 pyramid, 1 FAST score map, 2 NMS map, 3 blurred pyramid */
+ * which = 0 pyramid, 2 NMS map (FAST score where the pixel survived 3x3 NMS and the 31-px border
+ * filter, else 0), 3 blurred pyramid.  (The FAST score map before NMS is never materialised by the
+ * fused kernel; which = 1 is rejected.)  ORB handles only. */
 int rpe_orb_debug_fetch(rpe_handle *h, int index, int which, uint8_t *h_out);
 int64_t rpe_orb_pyramid_pixels(const rpe_handle *h);
 
@@ -194,7 +221,8 @@ int rpe_sift_detect_and_compute(rpe_handle *h, const uint8_t *h_imgs, int n_imag
 int64_t rpe_sift_debug_gauss(rpe_handle *h, int index, float *out);
 
 /* replaces BFMatcher(NORM_L2, crossCheck=True).match + sorted + truncate (pose_estimator.py:127-131,
- * :144-151) for SIFT descriptors (integer-valued f32, B*cap*128 each).  dist: f32 L2 distances. */
+ * :144-151) for byte-valued descriptors given as f32: SIFT handles B*cap*128 each (cv2 returns SIFT descriptors as
+ * integer-valued f32), ORB handles created with NORM_L2 B*cap*32 each.  dist: f32 L2 distances. */
 int rpe_match_l2(rpe_handle *h, const float *h_desc1, const int32_t *n1, const float *h_desc2,
                  const int32_t *n2, int B, int32_t *qidx, int32_t *tidx, float *dist, int32_t *n_matches);
 
@@ -221,6 +249,16 @@ enum {
 int rpe_set_profiling(rpe_handle *h, int enable);
 int rpe_get_stage_ms(rpe_handle *h, float *ms /* RPE_STAGE_COUNT */);
 const char *rpe_stage_name(int stage);
+
+/* ---------------------------------------------------- roofline calibration */
+/* Measured vector-instruction ISSUE rate of this device (wave-instructions per second, whole chip) for one
+ * instruction kind at `waves_per_simd` (1..8) resident waves per SIMD: the roof bench.py prices the VALU-bound
+ * kernels against.  kind: 0 v_xor+v_bcnt (Hamming), 1 v_pk_min/max_i16 (FAST pair test), 2 v_perm_b32,
+ * 3 v_dot4_u32_u8, 4 v_min3/v_max3_i32 (FAST score), 5 v_mad_u32_u24, 6 v_mul_f64+v_add_f64 (RANSAC, pose),
+ * 7 v_fma_f64.  rpe_calibrate_hbm: measured 16-B-per-lane streaming read rate (bytes/s). */
+int rpe_calibrate_valu(rpe_handle *h, int kind, int waves_per_simd, double *wave_insts_per_s);
+const char *rpe_calibrate_valu_name(int kind);
+int rpe_calibrate_hbm(rpe_handle *h, double *bytes_per_s);
 
 #ifdef __cplusplus
 }

@@ -407,14 +407,14 @@ int orc_find_essential(const float *pts1, const float *pts2, int M, const double
     double models[90];
     int ok = 0;
     if (M == 5) {
-        /* ptsetreg.cpp: count == modelPoints -> runKernel on all points; OpenCV
-         * returns every model stacked; this restatement keeps the first. */
+        /* ptsetreg.cpp: count == modelPoints -> runKernel on all points; OpenCV returns every model stacked
+         * (3n x 3).  E keeps the first; the return value is n so that callers can tell. */
         int nm = orc_five_point(n1, n2, models);
         if (nm > 0) {
             memcpy(E, models, sizeof(double) * 9);
             if (mask) memset(mask, 1, (size_t)M);
-            li.found = 1; li.best_count = 5; li.best_iter = 0; li.best_model = 0; li.iters_run = 1;
-            ok = 1;
+            li.found = nm; li.best_count = 5; li.best_iter = 0; li.best_model = 0; li.iters_run = 1;
+            ok = nm;                      /* > 1: cv2 hands back nm stacked 3x3 blocks */
         }
     } else {
         int niters = max_iters, best = 0;
@@ -608,7 +608,9 @@ static void *pose_worker(void *arg)
         o->n_matches = M;
         if (M < 5) { o->status = ORC_INSUFFICIENT_MATCHES; continue; }
         double E[9];
-        if (!orc_find_essential(p1, p2, M, j->K, 0.999, 1.0, 1000, E, NULL, NULL)) { o->status = ORC_NO_ESSENTIAL; continue; }
+        const int ne = orc_find_essential(p1, p2, M, j->K, 0.999, 1.0, 1000, E, NULL, NULL);
+        if (!ne) { o->status = ORC_NO_ESSENTIAL; continue; }
+        if (ne > 1) { o->status = ORC_AMBIGUOUS_ESSENTIAL; continue; }
         o->inliers = orc_recover_pose(E, p1, p2, M, j->K, o->R, o->t);
         o->status = ORC_OK;
     }

@@ -91,3 +91,61 @@ int orc_match_l2(const float *d1, int n1, const float *d2, int n2, int dim,
     free(m); free(best_d); free(best_t);
     return n;
 }
+
+/* ------------------------------------------------------------------ Lowe ratio (extension)
+ * NOT in the reference (it uses crossCheck, pose_estimator.py:131); named by the project brief.  Restates
+ * the usual cv2 idiom
+ *     good = [m for m, n in BFMatcher(norm).knnMatch(desc1, desc2, k=2) if m.distance < ratio * n.distance]
+ * followed by the reference's own sorted(key=distance)[:max_matches].  batchDistance keeps the K best trains
+ * per query with a strict '<' insertion while scanning trains in ascending order: ties keep the lower train
+ * index.  The ratio comparison is Python's: both distances as doubles.  Queries with fewer than two candidates
+ * emit nothing. */
+int orc_match_hamming_ratio(const uint8_t *d1, int n1, const uint8_t *d2, int n2, double ratio,
+                            int max_matches, int32_t *qidx, int32_t *tidx, int32_t *dist)
+{
+    if (n1 <= 0 || n2 < 2) return 0;
+    int *best_d = (int *)malloc(sizeof(int) * (size_t)n1);
+    int *best_t = (int *)malloc(sizeof(int) * (size_t)n1);
+    for (int i = 0; i < n1; ++i) {
+        int b = INT_MAX, s = INT_MAX, bj = -1;
+        for (int j = 0; j < n2; ++j) {
+            int d = hamming32(d1 + 32 * (size_t)i, d2 + 32 * (size_t)j);
+            if (d < b) { s = b; b = d; bj = j; }
+            else if (d < s) s = d;
+        }
+        best_t[i] = ((double)b < ratio * (double)s) ? bj : -1;
+        best_d[i] = b;
+    }
+    int n = 0;
+    int lim = max_matches >= 0 ? max_matches : INT_MAX;
+    for (int d = 0; d <= 256 && n < lim; ++d)
+        for (int i = 0; i < n1 && n < lim; ++i)
+            if (best_t[i] >= 0 && best_d[i] == d) { qidx[n] = i; tidx[n] = best_t[i]; dist[n] = d; ++n; }
+    free(best_d); free(best_t);
+    return n;
+}
+
+int orc_match_l2_ratio(const float *d1, int n1, const float *d2, int n2, int dim, double ratio,
+                       int max_matches, int32_t *qidx, int32_t *tidx, float *dist)
+{
+    if (n1 <= 0 || n2 < 2) return 0;
+    l2m *m = (l2m *)malloc(sizeof(l2m) * (size_t)n1);
+    int n = 0;
+    for (int i = 0; i < n1; ++i) {
+        float b = INFINITY, s = INFINITY; int bj = -1;
+        for (int j = 0; j < n2; ++j) {
+            const float *a = d1 + (size_t)dim * i, *c = d2 + (size_t)dim * j;
+            float acc = 0.f;
+            for (int k = 0; k < dim; ++k) { float df = a[k] - c[k]; acc += df * df; }
+            float d = sqrtf(acc);
+            if (d < b) { s = b; b = d; bj = j; }
+            else if (d < s) s = d;
+        }
+        if ((double)b < ratio * (double)s) { m[n].d = b; m[n].q = i; m[n].t = bj; ++n; }
+    }
+    qsort(m, (size_t)n, sizeof(l2m), cmp_l2);
+    if (max_matches >= 0 && n > max_matches) n = max_matches;
+    for (int i = 0; i < n; ++i) { qidx[i] = m[i].q; tidx[i] = m[i].t; dist[i] = m[i].d; }
+    free(m);
+    return n;
+}

@@ -43,12 +43,12 @@ class RansacInfo(C.Structure):
 
 class PoseResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_kp1", C.c_int32), ("n_kp2", C.c_int32),
-                ("n_matches", C.c_int32), ("inliers", C.c_int32),
+                ("n_matches", C.c_int32), ("inliers", C.c_int32), ("overflow", C.c_int32),
                 ("R", C.c_double * 9), ("t", C.c_double * 3)]
 
 
 POSE_DTYPE = np.dtype([("status", "<i4"), ("n_kp1", "<i4"), ("n_kp2", "<i4"), ("n_matches", "<i4"),
-                       ("inliers", "<i4"), ("_pad", "<i4"), ("R", "<f8", (9,)), ("t", "<f8", (3,))])
+                       ("inliers", "<i4"), ("overflow", "<i4"), ("R", "<f8", (9,)), ("t", "<f8", (3,))])
 
 _lib = None
 
@@ -106,6 +106,24 @@ def match_l2(d1, d2, max_matches=500):
     return q[:n].copy(), t[:n].copy(), d[:n].copy()
 
 
+def match_hamming_ratio(d1, d2, ratio=0.75, max_matches=500):
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    n1, n2 = len(d1), len(d2)
+    cap = max(n1, 1)
+    q = np.zeros(cap, np.int32); t = np.zeros(cap, np.int32); d = np.zeros(cap, np.int32)
+    n = lib().orc_match_hamming_ratio(_p(d1), n1, _p(d2), n2, C.c_double(ratio), int(max_matches), _p(q), _p(t), _p(d))
+    return q[:n].copy(), t[:n].copy(), d[:n].copy()
+
+
+def match_l2_ratio(d1, d2, ratio=0.75, max_matches=500):
+    d1 = np.ascontiguousarray(d1, np.float32); d2 = np.ascontiguousarray(d2, np.float32)
+    n1, n2 = len(d1), len(d2)
+    cap = max(n1, 1)
+    q = np.zeros(cap, np.int32); t = np.zeros(cap, np.int32); d = np.zeros(cap, np.float32)
+    n = lib().orc_match_l2_ratio(_p(d1), n1, _p(d2), n2, d1.shape[1], C.c_double(ratio), int(max_matches), _p(q), _p(t), _p(d))
+    return q[:n].copy(), t[:n].copy(), d[:n].copy()
+
+
 def five_point(x1, x2):
     x1 = np.ascontiguousarray(x1, np.float64); x2 = np.ascontiguousarray(x2, np.float64)
     E = np.zeros((10, 9), np.float64)
@@ -145,12 +163,15 @@ def orb_layout(W, H, nfeatures):
     return L
 
 
-def orb_detect_and_compute(img, nfeatures=4000, fast_threshold=15, cap=None):
+def orb_detect_and_compute(img, nfeatures=4000, fast_threshold=15, cap=None, return_flags=False):
     img = np.ascontiguousarray(img, np.uint8)
     H, W = img.shape
     cap = cap or nfeatures + 64
     kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
-    n = lib().orc_orb_detect_and_compute(_p(img), W, H, nfeatures, fast_threshold, _p(kps), _p(desc), cap)
+    flags = C.c_uint32(0)
+    n = lib().orc_orb_detect_and_compute_ex(_p(img), W, H, nfeatures, fast_threshold, _p(kps), _p(desc), cap, C.byref(flags))
+    if return_flags:
+        return kps[:n].copy(), desc[:n].copy(), int(flags.value)
     return kps[:n].copy(), desc[:n].copy()
 
 
@@ -196,14 +217,17 @@ def orb_pattern():
     return np.array([p[i] for i in range(1024)], np.int8).reshape(256, 4)
 
 
-def estimate_pose(img1, img2, K, nfeatures=4000, max_matches=500):
+def estimate_pose(img1, img2, K, nfeatures=4000, max_matches=500, norm="Hamming", ratio=None):
+    """max_matches None = the reference's 'no truncation' (pose_estimator.py:150-151)."""
     img1 = np.ascontiguousarray(img1, np.uint8); img2 = np.ascontiguousarray(img2, np.uint8)
     K = np.ascontiguousarray(K, np.float64)
     H, W = img1.shape
     res = PoseResult()
-    lib().orc_estimate_pose(_p(img1), _p(img2), W, H, _p(K), nfeatures, max_matches, C.byref(res))
+    mm = -1 if max_matches is None else int(max_matches)
+    lib().orc_estimate_pose_orb_ratio(_p(img1), _p(img2), W, H, _p(K), nfeatures, mm, 1 if norm.upper() == "L2" else 0,
+                                      C.c_double(ratio if ratio else 0.), C.byref(res))
     return {"status": res.status, "n_kp1": res.n_kp1, "n_kp2": res.n_kp2, "n_matches": res.n_matches,
-            "inliers": res.inliers, "R": np.array(res.R).reshape(3, 3), "t": np.array(res.t).reshape(3, 1)}
+            "inliers": res.inliers, "overflow": res.overflow, "R": np.array(res.R).reshape(3, 3), "t": np.array(res.t).reshape(3, 1)}
 
 
 def set_ransac_seed(seed=0xFFFFFFFFFFFFFFFF):
@@ -245,13 +269,16 @@ def pose_from_points_batch(pts, n_matches, K, nthreads=1):
 SIFT_KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4")])
 
 
-def sift_detect_and_compute(img, nfeatures=0, seed_cap=None, cap=None):
+def sift_detect_and_compute(img, nfeatures=0, seed_cap=None, cap=None, return_flags=False):
     img = np.ascontiguousarray(img, np.uint8)
     H, W = img.shape
     seed_cap = seed_cap or max(16384, 4 * W * H // 16)      # the HIP path's workspace rule
     cap = cap or (nfeatures + 64 if nfeatures > 0 else 4 * seed_cap)
     kps = np.zeros(cap, SIFT_KP_DTYPE); desc = np.zeros((cap, 128), np.float32)
-    n = lib().orc_sift_detect_and_compute(_p(img), W, H, int(nfeatures), int(seed_cap), _p(kps), _p(desc), cap)
+    flags = C.c_uint32(0)
+    n = lib().orc_sift_detect_and_compute_ex(_p(img), W, H, int(nfeatures), int(seed_cap), _p(kps), _p(desc), cap, C.byref(flags))
+    if return_flags:
+        return kps[:n].copy(), desc[:n].copy(), int(flags.value)
     return kps[:n].copy(), desc[:n].copy()
 
 

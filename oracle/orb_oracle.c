@@ -310,6 +310,13 @@ static float kth_largest_f(const float *v, int n, int k) /* k is 1-based */
 int orc_orb_detect_and_compute(const uint8_t *img, int W, int H, int nfeatures,
                                int fast_threshold, orc_keypoint *kps, uint8_t *desc, int cap)
 {
+    return orc_orb_detect_and_compute_ex(img, W, H, nfeatures, fast_threshold, kps, desc, cap, NULL);
+}
+
+int orc_orb_detect_and_compute_ex(const uint8_t *img, int W, int H, int nfeatures,
+                                  int fast_threshold, orc_keypoint *kps, uint8_t *desc, int cap, uint32_t *flags)
+{
+    uint32_t ovf = 0;
     init_umax();
     orc_orb_layout L;
     orc_orb_layout_init(W, H, nfeatures, &L);
@@ -317,7 +324,7 @@ int orc_orb_detect_and_compute(const uint8_t *img, int W, int H, int nfeatures,
     uint8_t *smap = pyr + L.total, *nmap = smap + L.total;
     orc_orb_build_pyramid(img, W, H, &L, pyr);
     int nk = 0;
-    for (int l = 0; l < NLEVELS && nk < cap; ++l) {
+    for (int l = 0; l < NLEVELS; ++l) {
         int w = L.w[l], h = L.h[l], q = L.quota[l];
         if (w <= 2 * EDGE || h <= 2 * EDGE || q <= 0) continue;
         const uint8_t *lv = pyr + L.offset[l];
@@ -336,9 +343,11 @@ int orc_orb_detect_and_compute(const uint8_t *img, int W, int H, int nfeatures,
         if (total > n2) { int acc = 0; for (tau = 255; tau > 0; --tau) { acc += hist[tau]; if (acc >= n2) break; } }
         int ccap = 4 * q + 256, nc = 0;
         cand_t *cd = (cand_t *)malloc(sizeof(cand_t) * (size_t)ccap);
-        for (int y = EDGE; y < h - EDGE && nc < ccap; ++y) for (int x = EDGE; x < w - EDGE && nc < ccap; ++x) {
+        for (int y = EDGE; y < h - EDGE; ++y) for (int x = EDGE; x < w - EDGE; ++x) {
             int v = nm[(size_t)y * w + x];
-            if (v >= tau && v) { cd[nc].x = x; cd[nc].y = y; cd[nc].score = v; cd[nc].resp = harris_response(lv, w, x, y); ++nc; }
+            if (!(v >= tau && v)) continue;
+            if (nc >= ccap) { ovf |= ORC_OVF_ORB_CANDIDATES; continue; }     /* workspace cap: first ccap in raster order */
+            cd[nc].x = x; cd[nc].y = y; cd[nc].score = v; cd[nc].resp = harris_response(lv, w, x, y); ++nc;
         }
         /* retainBest(quota) on the Harris response */
         float th = -INFINITY;
@@ -360,8 +369,9 @@ int orc_orb_detect_and_compute(const uint8_t *img, int W, int H, int nfeatures,
         } else if (g_variant[1] == 2) {
             for (int a = 0; a < no / 2; ++a) { int t = ord[a]; ord[a] = ord[no - 1 - a]; ord[no - 1 - a] = t; }
         }
-        for (int oi = 0; oi < no && nk < cap; ++oi) {
+        for (int oi = 0; oi < no; ++oi) {
             const int i = ord[oi];
+            if (nk >= cap) { ovf |= ORC_OVF_ORB_KEYPOINTS; break; }           /* workspace cap: level-major, raster */
             orc_keypoint *k = &kps[nk++];
             k->lx = cd[i].x; k->ly = cd[i].y; k->octave = l; k->response = cd[i].resp;
             k->angle = ic_angle(lv, w, cd[i].x, cd[i].y);
@@ -401,6 +411,7 @@ int orc_orb_detect_and_compute(const uint8_t *img, int W, int H, int nfeatures,
         }
     }
     free(pyr);
+    if (flags) *flags = ovf;
     return nk;
 }
 
@@ -410,20 +421,32 @@ int orc_orb_detect_and_compute(const uint8_t *img, int W, int H, int nfeatures,
  * re-extracting features. */
 static int estimate_pose_ex(const uint8_t *img1, const uint8_t *img2, int W, int H,
                             const double *K, int nfeatures, int max_matches,
-                            orc_pose_result *out, float *pts_out)
+                            orc_pose_result *out, float *pts_out, int norm, double ratio)
 {
     memset(out, 0, sizeof(*out));
     int cap = nfeatures + 64;
     orc_keypoint *k1 = (orc_keypoint *)malloc(sizeof(orc_keypoint) * 2 * (size_t)cap), *k2 = k1 + cap;
     uint8_t *d1 = (uint8_t *)malloc(64 * (size_t)cap), *d2 = d1 + 32 * (size_t)cap;
-    int n1 = orc_orb_detect_and_compute(img1, W, H, nfeatures, 15, k1, d1, cap);
-    int n2 = orc_orb_detect_and_compute(img2, W, H, nfeatures, 15, k2, d2, cap);
-    out->n_kp1 = n1; out->n_kp2 = n2;
+    uint32_t f1 = 0, f2 = 0;
+    int n1 = orc_orb_detect_and_compute_ex(img1, W, H, nfeatures, 15, k1, d1, cap, &f1);
+    int n2 = orc_orb_detect_and_compute_ex(img2, W, H, nfeatures, 15, k2, d2, cap, &f2);
+    out->n_kp1 = n1; out->n_kp2 = n2; out->overflow = (int32_t)(f1 | f2);
     int mm = max_matches >= 0 ? max_matches : cap;
     int32_t *qi = (int32_t *)malloc(sizeof(int32_t) * 3 * (size_t)cap), *ti = qi + cap, *di = ti + cap;
     float *p1 = (float *)malloc(sizeof(float) * 4 * (size_t)cap), *p2 = p1 + 2 * (size_t)cap;
     if (n1 == 0 || n2 == 0) { out->status = ORC_NO_DESCRIPTORS; goto done; }
-    int M = orc_match_hamming(d1, n1, d2, n2, mm, qi, ti, di);
+    int M;
+    if (norm == 1) {
+        /* BFMatcher(NORM_L2) on the ORB bytes (pose_estimator.py:115-131 builds any norm for any extractor) */
+        float *fd = (float *)malloc(sizeof(float) * 32 * (size_t)(n1 + n2)), *dist = (float *)malloc(sizeof(float) * (size_t)cap);
+        for (size_t e = 0; e < 32 * (size_t)n1; ++e) fd[e] = (float)d1[e];
+        for (size_t e = 0; e < 32 * (size_t)n2; ++e) fd[32 * (size_t)n1 + e] = (float)d2[e];
+        M = ratio > 0. ? orc_match_l2_ratio(fd, n1, fd + 32 * (size_t)n1, n2, 32, ratio, mm, qi, ti, dist)
+                       : orc_match_l2(fd, n1, fd + 32 * (size_t)n1, n2, 32, mm, qi, ti, dist);
+        free(fd); free(dist);
+    } else
+        M = ratio > 0. ? orc_match_hamming_ratio(d1, n1, d2, n2, ratio, mm, qi, ti, di)
+                       : orc_match_hamming(d1, n1, d2, n2, mm, qi, ti, di);
     out->n_matches = M;
     if (M < 5) { out->status = ORC_INSUFFICIENT_MATCHES; goto done; }
     for (int i = 0; i < M; ++i) {
@@ -435,7 +458,11 @@ static int estimate_pose_ex(const uint8_t *img1, const uint8_t *img2, int W, int
         memcpy(pts_out + 2 * (size_t)max_matches, p2, sizeof(float) * 2 * (size_t)M);
     }
     double E[9];
-    if (!orc_find_essential(p1, p2, M, K, 0.999, 1.0, 1000, E, NULL, NULL)) { out->status = ORC_NO_ESSENTIAL; goto done; }
+    {
+        const int ne = orc_find_essential(p1, p2, M, K, 0.999, 1.0, 1000, E, NULL, NULL);
+        if (!ne) { out->status = ORC_NO_ESSENTIAL; goto done; }
+        if (ne > 1) { out->status = ORC_AMBIGUOUS_ESSENTIAL; goto done; }
+    }
     out->inliers = orc_recover_pose(E, p1, p2, M, K, out->R, out->t);
     out->status = ORC_OK;
 done:
@@ -447,7 +474,19 @@ int orc_estimate_pose(const uint8_t *img1, const uint8_t *img2, int W, int H,
                       const double *K, int nfeatures, int max_matches,
                       orc_pose_result *out)
 {
-    return estimate_pose_ex(img1, img2, W, H, K, nfeatures, max_matches, out, NULL);
+    return estimate_pose_ex(img1, img2, W, H, K, nfeatures, max_matches, out, NULL, 0, 0.);
+}
+
+int orc_estimate_pose_orb(const uint8_t *img1, const uint8_t *img2, int W, int H,
+                          const double *K, int nfeatures, int max_matches, int norm, orc_pose_result *out)
+{
+    return estimate_pose_ex(img1, img2, W, H, K, nfeatures, max_matches, out, NULL, norm, 0.);
+}
+
+int orc_estimate_pose_orb_ratio(const uint8_t *img1, const uint8_t *img2, int W, int H,
+                                const double *K, int nfeatures, int max_matches, int norm, double ratio, orc_pose_result *out)
+{
+    return estimate_pose_ex(img1, img2, W, H, K, nfeatures, max_matches, out, NULL, norm, ratio);
 }
 
 #include <pthread.h>
@@ -460,7 +499,7 @@ static void *worker(void *arg)
     size_t sz = (size_t)j->W * j->H;
     for (int b = j->tid; b < j->B; b += j->nt)
         estimate_pose_ex(j->i1 + sz * b, j->i2 + sz * b, j->W, j->H, j->K, j->nf, j->mm, &j->out[b],
-                         j->pts ? j->pts + 4 * (size_t)j->mm * b : NULL);
+                         j->pts ? j->pts + 4 * (size_t)j->mm * b : NULL, 0, 0.);
     return NULL;
 }
 void orc_estimate_pose_batch_pts(const uint8_t *imgs1, const uint8_t *imgs2, int B, int W, int H,

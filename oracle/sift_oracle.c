@@ -385,6 +385,13 @@ static int kp_cmp(const void *a, const void *b) { return kp_less((const sift_kp 
 int orc_sift_detect_and_compute(const uint8_t *img, int W, int H, int nfeatures, int seed_cap,
                                 orc_sift_keypoint *kps, float *desc, int cap)
 {
+    return orc_sift_detect_and_compute_ex(img, W, H, nfeatures, seed_cap, kps, desc, cap, NULL);
+}
+
+int orc_sift_detect_and_compute_ex(const uint8_t *img, int W, int H, int nfeatures, int seed_cap,
+                                   orc_sift_keypoint *kps, float *desc, int cap, uint32_t *flags)
+{
+    uint32_t ovf = 0;
     sift_geo g;
     sift_geometry(W, H, &g);
     float *gp = (float *)malloc(sizeof(float) * g.gtotal);
@@ -412,7 +419,7 @@ int orc_sift_detect_and_compute(const uint8_t *img, int W, int H, int nfeatures,
                                 if (v < val) ismin = 0;
                             }
                     if (!(ismax || ismin)) continue;
-                    if (nseeds >= seed_cap) continue;
+                    if (nseeds >= seed_cap) { ovf |= ORC_OVF_SIFT_SEEDS; continue; }
                     ++nseeds;
                     int l = i, rr = r, cc = c; float xi, xr, xc, contr;
                     if (!adjust_extremum(&dc, &l, &rr, &cc, &xi, &xr, &xc, &contr)) continue;
@@ -435,7 +442,7 @@ int orc_sift_detect_and_compute(const uint8_t *img, int W, int H, int nfeatures,
                             bin = bin < 0 ? ORI_BINS + bin : bin >= ORI_BINS ? bin - ORI_BINS : bin;
                             kp.angle = 360.f - (360.f / ORI_BINS) * bin;
                             if (fabsf(kp.angle - 360.f) < FLT_EPSILON) kp.angle = 0.f;
-                            if (nk < kcap) tmp[nk++] = kp;
+                            if (nk < kcap) tmp[nk++] = kp; else ovf |= ORC_OVF_SIFT_RAW;
                         }
                     }
                 }
@@ -443,6 +450,7 @@ int orc_sift_detect_and_compute(const uint8_t *img, int W, int H, int nfeatures,
     }
     /* retainBest(nfeatures): all keypoints with response >= the n-th best */
     if (nfeatures > 0 && nk > nfeatures) {
+        ovf |= ORC_OVF_SIFT_CAP;          /* the cap bites: the reference's SIFT_create() keeps all nk */
         float *rs = (float *)malloc(sizeof(float) * (size_t)nk);
         for (int i = 0; i < nk; ++i) rs[i] = tmp[i].response;
         for (int i = 0; i < nfeatures; ++i) { int m = i; for (int j = i + 1; j < nk; ++j) if (rs[j] > rs[m]) m = j; float t = rs[i]; rs[i] = rs[m]; rs[m] = t; }
@@ -452,7 +460,8 @@ int orc_sift_detect_and_compute(const uint8_t *img, int W, int H, int nfeatures,
         nk = m; free(rs);
     }
     qsort(tmp, (size_t)nk, sizeof(sift_kp), kp_cmp);
-    if (nk > cap) nk = cap;
+    if (nk > cap) { nk = cap; ovf |= ORC_OVF_SIFT_KEYPOINTS; }
+    if (flags) *flags = ovf;
     for (int i = 0; i < nk; ++i) {
         sift_kp kp = tmp[i];
         /* descriptor is computed at the un-halved coordinates (octave index o, scale 1/(1<<o)) */
@@ -494,9 +503,10 @@ int orc_estimate_pose_sift(const uint8_t *img1, const uint8_t *img2, int W, int 
     orc_sift_keypoint *k1 = (orc_sift_keypoint *)malloc(sizeof(orc_sift_keypoint) * 2 * (size_t)cap), *k2 = k1 + cap;
     float *d1 = (float *)malloc(sizeof(float) * 256 * (size_t)cap), *d2 = d1 + 128 * (size_t)cap;
     int seed_cap = (int)(((long long)4 * W * H) / 16); if (seed_cap < 16384) seed_cap = 16384;   /* rule of the HIP path */
-    int n1 = orc_sift_detect_and_compute(img1, W, H, nfeatures, seed_cap, k1, d1, cap);
-    int n2 = orc_sift_detect_and_compute(img2, W, H, nfeatures, seed_cap, k2, d2, cap);
-    out->n_kp1 = n1; out->n_kp2 = n2;
+    uint32_t f1 = 0, f2 = 0;
+    int n1 = orc_sift_detect_and_compute_ex(img1, W, H, nfeatures, seed_cap, k1, d1, cap, &f1);
+    int n2 = orc_sift_detect_and_compute_ex(img2, W, H, nfeatures, seed_cap, k2, d2, cap, &f2);
+    out->n_kp1 = n1; out->n_kp2 = n2; out->overflow = (int32_t)(f1 | f2);
     int mm = max_matches >= 0 ? max_matches : cap;
     int32_t *qi = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)cap), *ti = qi + cap;
     float *di = (float *)malloc(sizeof(float) * (size_t)cap);
@@ -510,7 +520,11 @@ int orc_estimate_pose_sift(const uint8_t *img1, const uint8_t *img2, int W, int 
         p2[2 * i] = k2[ti[i]].x; p2[2 * i + 1] = k2[ti[i]].y;
     }
     double E[9];
-    if (!orc_find_essential(p1, p2, M, K, 0.999, 1.0, 1000, E, NULL, NULL)) { out->status = ORC_NO_ESSENTIAL; goto done; }
+    {
+        const int ne = orc_find_essential(p1, p2, M, K, 0.999, 1.0, 1000, E, NULL, NULL);
+        if (!ne) { out->status = ORC_NO_ESSENTIAL; goto done; }
+        if (ne > 1) { out->status = ORC_AMBIGUOUS_ESSENTIAL; goto done; }
+    }
     out->inliers = orc_recover_pose(E, p1, p2, M, K, out->R, out->t);
     out->status = ORC_OK;
 done:

@@ -11,11 +11,16 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RPE_LIB", os.path.join(_HERE, "librpe_amd.so"))   # RPE_LIB: diagnostic builds only
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 ORB_LEVELS = 12
-PAIR_OK, PAIR_NO_DESCRIPTORS, PAIR_INSUFFICIENT_MATCHES, PAIR_NO_ESSENTIAL = 0, 1, 2, 3
+PAIR_OK, PAIR_NO_DESCRIPTORS, PAIR_INSUFFICIENT_MATCHES, PAIR_NO_ESSENTIAL, PAIR_AMBIGUOUS_ESSENTIAL = 0, 1, 2, 3, 4
 FEATURE_ORB, FEATURE_SIFT = 0, 1
 NORM_HAMMING, NORM_L2 = 0, 1
+MATCH_CROSSCHECK, MATCH_RATIO = 0, 1
+# capacity flags (rpe_fetch_overflow)
+OVF_ORB_CANDIDATES, OVF_ORB_KEYPOINTS = 1 << 0, 1 << 1
+OVF_SIFT_SEEDS, OVF_SIFT_RAW, OVF_SIFT_PREFILTER, OVF_SIFT_CAP, OVF_SIFT_KEYPOINTS = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
+CALIB_KINDS = 8
 STAGE_COUNT = 12
 ORDER_BGR, ORDER_RGB = 0, 1
 
@@ -29,6 +34,7 @@ EXPORTS = [
     "rpe_sift_detect_and_compute", "rpe_sift_debug_gauss", "rpe_match_l2",
     "rpe_estimate_stream", "rpe_enqueue_stream_device",
     "rpe_bgr_to_gray_device", "rpe_bgr_to_gray", "rpe_lsd_detect",
+    "rpe_fetch_overflow", "rpe_calibrate_valu", "rpe_calibrate_valu_name", "rpe_calibrate_hbm",
 ]
 
 
@@ -36,7 +42,8 @@ class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
                 ("max_batch", C.c_int32), ("feature_method", C.c_int32), ("norm_type", C.c_int32),
                 ("max_matches", C.c_int32), ("nfeatures", C.c_int32), ("fast_threshold", C.c_int32),
-                ("ransac_max_iters", C.c_int32), ("ransac_prob", C.c_double), ("ransac_threshold", C.c_double)]
+                ("ransac_max_iters", C.c_int32), ("ransac_prob", C.c_double), ("ransac_threshold", C.c_double),
+                ("match_mode", C.c_int32), ("reserved0", C.c_int32), ("match_ratio", C.c_double)]
 
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("angle", "<f4"), ("response", "<f4"),
@@ -103,6 +110,10 @@ def load():
     lib.rpe_bgr_to_gray_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]; lib.rpe_bgr_to_gray_device.restype = C.c_int
     lib.rpe_bgr_to_gray.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]; lib.rpe_bgr_to_gray.restype = C.c_int
     lib.rpe_lsd_detect.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, i32p]; lib.rpe_lsd_detect.restype = C.c_int
+    lib.rpe_fetch_overflow.argtypes = [vp, C.c_int, vp]; lib.rpe_fetch_overflow.restype = C.c_int
+    lib.rpe_calibrate_valu.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]; lib.rpe_calibrate_valu.restype = C.c_int
+    lib.rpe_calibrate_valu_name.argtypes = [C.c_int]; lib.rpe_calibrate_valu_name.restype = C.c_char_p
+    lib.rpe_calibrate_hbm.argtypes = [vp, C.POINTER(C.c_double)]; lib.rpe_calibrate_hbm.restype = C.c_int
     _lib = lib
     return lib
 
@@ -129,7 +140,8 @@ class Engine:
 
     def __init__(self, width, height, max_batch=1, nfeatures=4000, max_matches=500, device=0,
                  feature_method=FEATURE_ORB, norm_type=NORM_HAMMING, fast_threshold=15,
-                 ransac_max_iters=1000, ransac_prob=0.999, ransac_threshold=1.0):
+                 ransac_max_iters=1000, ransac_prob=0.999, ransac_threshold=1.0,
+                 match_mode=MATCH_CROSSCHECK, match_ratio=0.75):
         self.lib = load()
         cfg = Config()
         self.lib.rpe_default_config(C.byref(cfg))
@@ -137,6 +149,7 @@ class Engine:
         cfg.feature_method = feature_method; cfg.norm_type = norm_type
         cfg.max_matches = max_matches; cfg.nfeatures = nfeatures; cfg.fast_threshold = fast_threshold
         cfg.ransac_max_iters = ransac_max_iters; cfg.ransac_prob = ransac_prob; cfg.ransac_threshold = ransac_threshold
+        cfg.match_mode = match_mode; cfg.match_ratio = match_ratio
         self.cfg = cfg
         h = C.c_void_p()
         rc = self.lib.rpe_create(C.byref(cfg), C.byref(h))
@@ -146,6 +159,7 @@ class Engine:
         self.width, self.height, self.max_batch = width, height, max_batch
         self.max_matches = max_matches
         self.kcap = self.lib.rpe_keypoint_capacity(h)
+        self.desc_dim = 128 if feature_method == FEATURE_SIFT else 32
 
     def close(self):
         if getattr(self, "h", None):
@@ -246,6 +260,12 @@ class Engine:
         self._chk(self.lib.rpe_fetch_results(self.h, B, _p(R), _p(t), _p(inl), _p(nm), _p(st)))
         return R, t, inl, nm, st
 
+    def fetch_overflow(self, n_pairs):
+        """OVF_* capacity flags of the last batch / stream, one word per pair."""
+        f = np.zeros(n_pairs, np.uint32)
+        self._chk(self.lib.rpe_fetch_overflow(self.h, n_pairs, _p(f)))
+        return f
+
     def fetch_matched_points(self, B):
         p1 = np.zeros((B, self.max_matches, 2), np.float32); p2 = np.zeros_like(p1)
         self._chk(self.lib.rpe_fetch_matched_points(self.h, B, _p(p1), _p(p2)))
@@ -281,7 +301,7 @@ class Engine:
 
     def match_l2(self, desc1, n1, desc2, n2):
         B = len(n1)
-        d1 = np.zeros((B, self.kcap, 128), np.float32); d2 = np.zeros_like(d1)
+        d1 = np.zeros((B, self.kcap, self.desc_dim), np.float32); d2 = np.zeros_like(d1)
         for i in range(B):
             d1[i, :n1[i]] = desc1[i][:n1[i]]; d2[i, :n2[i]] = desc2[i][:n2[i]]
         n1 = np.ascontiguousarray(n1, np.int32); n2 = np.ascontiguousarray(n2, np.int32)
@@ -325,6 +345,18 @@ class Engine:
         R = np.zeros((B, 3, 3)); t = np.zeros((B, 3, 1)); inl = np.zeros(B, np.int32)
         self._chk(self.lib.rpe_recover_pose(self.h, _p(E), _p(p1), _p(p2), _p(m), B, _p(K), _p(R), _p(t), _p(inl)))
         return R, t, inl
+
+    # ---- roofline calibration
+    def calibrate_valu(self, kind, waves_per_simd):
+        """(instruction name, measured wave-instructions per second of the whole chip)"""
+        v = C.c_double(0.)
+        self._chk(self.lib.rpe_calibrate_valu(self.h, kind, waves_per_simd, C.byref(v)))
+        return self.lib.rpe_calibrate_valu_name(kind).decode(), float(v.value)
+
+    def calibrate_hbm(self):
+        v = C.c_double(0.)
+        self._chk(self.lib.rpe_calibrate_hbm(self.h, C.byref(v)))
+        return float(v.value)
 
     # ---- profiling
     def set_profiling(self, on):

@@ -600,18 +600,21 @@ __device__ __forceinline__ int update_niters(const double *nit_denom, const int 
 __global__ __launch_bounds__(256) void ransac_score_kernel(const double2 *__restrict__ n1, const double2 *__restrict__ n2,
                                                             const RpeRansacState *__restrict__ st, const double *__restrict__ models,
                                                             const int *__restrict__ nmodels, const double *__restrict__ K,
-                                                            double threshold, int *__restrict__ counts, int max_matches)
+                                                            double threshold, int *__restrict__ counts, int max_matches, int use_lds)
 {
-    extern __shared__ double2 s_pts[];              // [2][M]
+    extern __shared__ double2 s_pts[];              // [2][max_matches] when the points fit LDS (use_lds)
     __shared__ int s_nm[64], s_first[65];
     const int pair = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const RpeRansacState s = st[pair];
     if (s.done || s.M <= 5 || s.next_iter + grp * 64 >= s.niters) return;
     const int M = s.M;
-    double2 *sp1 = s_pts, *sp2 = s_pts + max_matches;
-    for (int i = tid; i < M; i += 256) {
-        sp1[i] = n1[(long long)pair * max_matches + i];
-        sp2[i] = n2[(long long)pair * max_matches + i];
+    // max_matches > 2048 ("no truncation" configurations): 32 B per match no longer fit the 64 KB of dynamic LDS;
+    // the points are then read from HBM / L2 directly (every wave walks the same 64 KB-scale array)
+    const double2 *sp1 = n1 + (long long)pair * max_matches, *sp2 = n2 + (long long)pair * max_matches;
+    if (use_lds) {
+        double2 *l1 = s_pts, *l2 = s_pts + max_matches;
+        for (int i = tid; i < M; i += 256) { l1[i] = sp1[i]; l2[i] = sp2[i]; }
+        sp1 = l1; sp2 = l2;
     }
     const long long slot0 = (long long)pair * RPE_RANSAC_MAXCHUNK + grp * 64;
     if (tid < 64) s_nm[tid] = nmodels[slot0 + tid];
@@ -668,9 +671,13 @@ __global__ __launch_bounds__(256) void ransac_update_kernel(RpeRansacState *__re
     const int M = s.M;
     const long long slot0 = (long long)pair * RPE_RANSAC_MAXCHUNK;
     int best = s.best_count, niters = s.niters, bk = -1, bm = -1;
+    int nstack = 0;
     if (M == 5) {
-        // ptsetreg.cpp: count == modelPoints -> runKernel on all points, first model kept
-        if (nmodels[slot0] > 0) { best = 5; bk = 0; bm = 0; s.best_iter = 0; s.best_model = 0; }
+        // ptsetreg.cpp: count == modelPoints -> runKernel on all points; cv2 returns EVERY model stacked (3n x 3).
+        // One model = a usable E; more than one is reported (found = n) and becomes RPE_PAIR_AMBIGUOUS_ESSENTIAL
+        // (the reference's recoverPose call then fails its 3x3 assertion, pose_estimator.py:533); E keeps the first.
+        nstack = nmodels[slot0];
+        if (nstack > 0) { best = 5; bk = 0; bm = 0; s.best_iter = 0; s.best_model = 0; }
         niters = 1;
         s.next_iter = 1;
         s.iters_run = 1;
@@ -743,9 +750,10 @@ __global__ __launch_bounds__(256) void ransac_update_kernel(RpeRansacState *__re
         RpeRansacState *d = st + pair;
         d->best_count = best; d->niters = niters; d->best_iter = s.best_iter; d->best_model = s.best_model;
         d->next_iter = s.next_iter; d->iters_run = s.iters_run;
-        d->found = best > 0;
+        const int fnd = (M == 5) ? nstack : (best > 0 ? 1 : 0);
+        d->found = fnd;
         d->done = s.next_iter >= niters;
-        found[pair] = best > 0;
+        found[pair] = fnd;
     }
 }
 
@@ -780,7 +788,8 @@ void rpe_launch_ransac(rpe_handle *h, int B, bool want_mask)
                        h->d_pts1, h->d_pts2, h->d_m_n, h->d_K, n1, n2, h->d_rstate, h->d_found, mm, it);
     // chunk schedule 64, 64, 128, 256, 512, 512, ...: most pairs stop inside the first 64 iterations;
     // launches are bound by single-wave latency, so long-running pairs get more waves per launch
-    const size_t lds = sizeof(double2) * 2 * (size_t)mm;
+    const int use_lds = mm <= 2048;
+    const size_t lds = use_lds ? sizeof(double2) * 2 * (size_t)mm : 0;
     int done_iters = 0, chunk = 64, nlaunch = 0;
     while (done_iters < it) {
         const int wpp = chunk / 64;
@@ -790,7 +799,7 @@ void rpe_launch_ransac(rpe_handle *h, int B, bool want_mask)
                            (const RpeRansacState *)h->d_rstate, (const double *)h->d_hyp, h->d_models, h->d_nmodels, B, wpp);
         hipLaunchKernelGGL(ransac_score_kernel, dim3(B, wpp), dim3(256), lds, h->stream,
                            n1, n2, (const RpeRansacState *)h->d_rstate, (const double *)h->d_models, (const int *)h->d_nmodels,
-                           (const double *)h->d_K, h->cfg.ransac_threshold, h->d_counts, mm);
+                           (const double *)h->d_K, h->cfg.ransac_threshold, h->d_counts, mm, use_lds);
         hipLaunchKernelGGL(ransac_update_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream,
                            h->d_rstate, (const double *)h->d_models, (const int *)h->d_nmodels, (const int *)h->d_counts,
                            (const double *)h->d_nit_denom, (const int *)h->d_nit_round, h->nit_num, h->d_E, h->d_found, chunk, B);
@@ -928,6 +937,7 @@ __global__ __launch_bounds__(256) void recover_pose_kernel(const double *__restr
     if (kp_count && (kp_count[pair] == 0 || kp_count[img2_base + pair] == 0)) stt = RPE_PAIR_NO_DESCRIPTORS;
     else if (M < 5) stt = RPE_PAIR_INSUFFICIENT_MATCHES;
     else if (found && !found[pair]) stt = RPE_PAIR_NO_ESSENTIAL;
+    else if (found && found[pair] > 1) stt = RPE_PAIR_AMBIGUOUS_ESSENTIAL;
     if (stt != RPE_PAIR_OK) {
         if (tid < 9) Rout[pair * 9 + tid] = (tid % 4 == 0) ? 1. : 0.;
         if (tid < 3) tout[pair * 3 + tid] = 0.;

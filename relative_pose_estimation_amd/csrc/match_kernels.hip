@@ -12,6 +12,13 @@
 // (strict '<', ascending query => lowest index on ties); every query keeps its best
 // elector through a packed (dist<<18 | trainIdx) LDS atomicMin (lowest train on ties).
 // The stable sort by distance is a bitonic sort of (dist<<16 | queryIdx) keys in LDS.
+//
+// RATIO = true is the opt-in extension named by the project brief and absent from the reference (which uses
+// crossCheck, pose_estimator.py:131): cv2's knnMatch(k=2) + Lowe's ratio test.  Roles swap: a lane owns a QUERY
+// descriptor, the TRAIN descriptors stream through LDS; the lane keeps its best (distance, lowest train index) and
+// second-best distance and emits the match iff  best < ratio * second  (compared in f64, as Python compares
+// m.distance < ratio * n.distance); queries with fewer than two candidates emit nothing.  Sort / truncation /
+// point gather are shared.
 #include "rpe_internal.h"
 
 #define QTILE 1024
@@ -24,9 +31,10 @@ __device__ __forceinline__ int ham256(const uint4 &a0, const uint4 &a1, const ui
     return d;
 }
 
+template <bool RATIO>
 __global__ __launch_bounds__(256) void match_hamming_kernel(const uint8_t *__restrict__ desc, const int *__restrict__ kp_count,
                                                              const float2 *__restrict__ kp_pt, int img2_base, int kcap,
-                                                             int max_matches,
+                                                             int max_matches, double ratio,
                                                              int *__restrict__ m_q, int *__restrict__ m_t, int *__restrict__ m_d,
                                                              int *__restrict__ m_n, float2 *__restrict__ pts1, float2 *__restrict__ pts2)
 {
@@ -41,34 +49,50 @@ __global__ __launch_bounds__(256) void match_hamming_kernel(const uint8_t *__res
     if (tid == 0) s_valid = 0;
     const uint4 *d1 = (const uint4 *)(desc + (long long)img1 * kcap * 32);
     const uint4 *d2 = (const uint4 *)(desc + (long long)img2 * kcap * 32);
-    for (int tc = 0; tc < n2; tc += 256) {
+    // owner descriptors (one per lane, in registers) x scanned descriptors (through LDS):
+    // crossCheck: owner = train j, scanned = queries; ratio: owner = query i, scanned = trains
+    const uint4 *d_own = RATIO ? d1 : d2, *d_scan = RATIO ? d2 : d1;
+    const int n_own = RATIO ? n1 : n2, n_scan = RATIO ? n2 : n1;
+    for (int tc = 0; tc < n_own; tc += 256) {
         const int j = tc + tid;
-        const bool valid = j < n2;
+        const bool valid = j < n_own;
         uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0;
-        if (valid) { t0 = d2[2 * j]; t1 = d2[2 * j + 1]; }
-        int bestd = 0x7FFFFFFF, besti = 0;
-        for (int qt = 0; qt < n1; qt += QTILE) {
-            const int nq = min(QTILE, n1 - qt);
+        if (valid) { t0 = d_own[2 * j]; t1 = d_own[2 * j + 1]; }
+        int bestd = 0x7FFFFFFF, besti = 0, second = 0x7FFFFFFF;
+        for (int qt = 0; qt < n_scan; qt += QTILE) {
+            const int nq = min(QTILE, n_scan - qt);
             __syncthreads();
-            for (int idx = tid; idx < nq * 2; idx += 256) s_q[idx] = d1[2 * qt + idx];
+            for (int idx = tid; idx < nq * 2; idx += 256) s_q[idx] = d_scan[2 * qt + idx];
             __syncthreads();
             int i = 0;
-            for (; i + 4 <= nq; i += 4) {
-                int da = ham256(s_q[2 * i], s_q[2 * i + 1], t0, t1);
-                int db = ham256(s_q[2 * i + 2], s_q[2 * i + 3], t0, t1);
-                int dc = ham256(s_q[2 * i + 4], s_q[2 * i + 5], t0, t1);
-                int dd = ham256(s_q[2 * i + 6], s_q[2 * i + 7], t0, t1);
-                if (da < bestd) { bestd = da; besti = qt + i; }
-                if (db < bestd) { bestd = db; besti = qt + i + 1; }
-                if (dc < bestd) { bestd = dc; besti = qt + i + 2; }
-                if (dd < bestd) { bestd = dd; besti = qt + i + 3; }
-            }
-            for (; i < nq; ++i) {
-                int da = ham256(s_q[2 * i], s_q[2 * i + 1], t0, t1);
-                if (da < bestd) { bestd = da; besti = qt + i; }
+            if (!RATIO) {
+                for (; i + 4 <= nq; i += 4) {
+                    int da = ham256(s_q[2 * i], s_q[2 * i + 1], t0, t1);
+                    int db = ham256(s_q[2 * i + 2], s_q[2 * i + 3], t0, t1);
+                    int dc = ham256(s_q[2 * i + 4], s_q[2 * i + 5], t0, t1);
+                    int dd = ham256(s_q[2 * i + 6], s_q[2 * i + 7], t0, t1);
+                    if (da < bestd) { bestd = da; besti = qt + i; }
+                    if (db < bestd) { bestd = db; besti = qt + i + 1; }
+                    if (dc < bestd) { bestd = dc; besti = qt + i + 2; }
+                    if (dd < bestd) { bestd = dd; besti = qt + i + 3; }
+                }
+                for (; i < nq; ++i) {
+                    int da = ham256(s_q[2 * i], s_q[2 * i + 1], t0, t1);
+                    if (da < bestd) { bestd = da; besti = qt + i; }
+                }
+            } else {
+                for (; i < nq; ++i) {
+                    const int da = ham256(s_q[2 * i], s_q[2 * i + 1], t0, t1);
+                    if (da < bestd) { second = bestd; bestd = da; besti = qt + i; }
+                    else if (da < second) second = da;
+                }
             }
         }
-        if (valid && n1 > 0) atomicMin(&s_best[besti], ((unsigned)bestd << 18) | (unsigned)j);
+        if (!RATIO) {
+            if (valid && n_scan > 0) atomicMin(&s_best[besti], ((unsigned)bestd << 18) | (unsigned)j);
+        } else if (valid && n_scan >= 2 && (double)bestd < ratio * (double)second) {
+            s_best[j] = ((unsigned)bestd << 18) | (unsigned)besti;          // owner j is the query, besti the train
+        }
     }
     __syncthreads();
     // (dist, queryIdx) keys; unmatched queries sort to the end
@@ -115,9 +139,14 @@ void rpe_launch_match(rpe_handle *h, int B)
 {
     const int kcap = h->lay.kcap;
     size_t lds = (size_t)QTILE * 32 + (size_t)kcap * 4;
-    hipLaunchKernelGGL(match_hamming_kernel, dim3(B), dim3(256), lds, h->stream,
-                       h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches,
-                       h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
+    if (h->cfg.match_mode == RPE_MATCH_RATIO)
+        hipLaunchKernelGGL((match_hamming_kernel<true>), dim3(B), dim3(256), lds, h->stream,
+                           h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches, h->cfg.match_ratio,
+                           h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
+    else
+        hipLaunchKernelGGL((match_hamming_kernel<false>), dim3(B), dim3(256), lds, h->stream,
+                           h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches, 0.0,
+                           h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
 }
 
 // ===================================================================== L2 (SIFT)
@@ -129,13 +158,16 @@ void rpe_launch_match(rpe_handle *h, int B)
 // Same selection semantics as the Hamming kernel; keys are 64-bit because the sort key is
 // the f32 distance (distinct integers can collide after sqrt -> tie broken by index).
 #define L2_QTILE 256
-#define L2_DIM 128
 
-__device__ __forceinline__ unsigned dot128_u8(const uint4 *q, const uint4 (&t)[8])
+// NQ = descriptor bytes / 16: 8 for SIFT (128 B), 2 for ORB descriptors matched with NORM_L2 (32 B; cv2 builds this
+// combination too, pose_estimator.py:115-131 -- batchDistance on CV_8U rows gives sqrt((float)sum of squared byte
+// differences), the same exact-integer form)
+template <int NQ>
+__device__ __forceinline__ unsigned dot_u8(const uint4 *q, const uint4 (&t)[NQ])
 {
     unsigned acc = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NQ; ++k) {
         const uint4 a = q[k];
         acc = __builtin_amdgcn_udot4(a.x, t[k].x, acc, false);
         acc = __builtin_amdgcn_udot4(a.y, t[k].y, acc, false);
@@ -149,44 +181,49 @@ __device__ __forceinline__ unsigned dot128_u8(const uint4 *q, const uint4 (&t)[8
 // all query tiles; the election lands in HBM through a packed 64-bit atomicMin per query
 // (integer atomics: order independent).  Splitting a pair over its train chunks gives kcap/256 times
 // more workgroups than one workgroup per pair (32-pair HD sub-batches left 7/8 of the CUs idle).
+template <int NQ, bool RATIO>
 __global__ __launch_bounds__(256) void match_l2_nearest_kernel(const uint8_t *__restrict__ desc, const int *__restrict__ kp_count,
-                                                                int img2_base, int kcap, unsigned long long *__restrict__ best)
+                                                                int img2_base, int kcap, double ratio, unsigned long long *__restrict__ best)
 {
-    __shared__ uint4 s_q[L2_QTILE * 8];                                         // 32 KB
+    constexpr int DIM = NQ * 16;
+    __shared__ uint4 s_q[L2_QTILE * NQ];                                        // 32 KB (SIFT) / 8 KB (ORB)
     __shared__ unsigned s_qn[L2_QTILE];                                         // |q|^2 of the tile
     const int tid = threadIdx.x, pair = blockIdx.y, tc = blockIdx.x * 256;
     const int img1 = pair, img2 = img2_base + pair;
     const int n1 = min(kp_count[img1], kcap), n2 = min(kp_count[img2], kcap);
-    if (tc >= n2 || n1 <= 0) return;
-    const uint4 *d1 = (const uint4 *)(desc + (long long)img1 * kcap * L2_DIM);
-    const uint4 *d2 = (const uint4 *)(desc + (long long)img2 * kcap * L2_DIM);
+    // crossCheck: a lane owns a train, queries stream through LDS; ratio (extension): a lane owns a query, trains stream
+    const int n_own = RATIO ? n1 : n2, n_scan = RATIO ? n2 : n1;
+    if (tc >= n_own || n_scan <= 0) return;
+    const uint4 *d1 = (const uint4 *)(desc + (long long)img1 * kcap * DIM);
+    const uint4 *d2 = (const uint4 *)(desc + (long long)img2 * kcap * DIM);
+    const uint4 *d_own = RATIO ? d1 : d2, *d_scan = RATIO ? d2 : d1;
     const int j = tc + tid;
-    const bool valid = j < n2;
-    uint4 t[8];
+    const bool valid = j < n_own;
+    uint4 t[NQ];
     unsigned tn = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        t[k] = valid ? d2[8 * j + k] : make_uint4(0, 0, 0, 0);
+    for (int k = 0; k < NQ; ++k) {
+        t[k] = valid ? d_own[NQ * j + k] : make_uint4(0, 0, 0, 0);
         tn = __builtin_amdgcn_udot4(t[k].x, t[k].x, tn, false); tn = __builtin_amdgcn_udot4(t[k].y, t[k].y, tn, false);
         tn = __builtin_amdgcn_udot4(t[k].z, t[k].z, tn, false); tn = __builtin_amdgcn_udot4(t[k].w, t[k].w, tn, false);
     }
-    float bestd = __builtin_inff();
+    float bestd = __builtin_inff(), second = __builtin_inff();
     int besti = -1;
-    for (int qt = 0; qt < n1; qt += L2_QTILE) {
-        const int nq = min(L2_QTILE, n1 - qt);
+    for (int qt = 0; qt < n_scan; qt += L2_QTILE) {
+        const int nq = min(L2_QTILE, n_scan - qt);
         __syncthreads();
         {
-            uint4 stage[8];
+            uint4 stage[NQ];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { const int idx = tid + 256 * q; stage[q] = idx < nq * 8 ? d1[8 * qt + idx] : make_uint4(0, 0, 0, 0); }
+            for (int q = 0; q < NQ; ++q) { const int idx = tid + 256 * q; stage[q] = idx < nq * NQ ? d_scan[NQ * qt + idx] : make_uint4(0, 0, 0, 0); }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) s_q[tid + 256 * q] = stage[q];
+            for (int q = 0; q < NQ; ++q) s_q[tid + 256 * q] = stage[q];
         }
         __syncthreads();
         if (tid < nq) {
             unsigned qn = 0;
-            for (int k = 0; k < 8; ++k) {
-                const uint4 a = s_q[8 * tid + k];
+            for (int k = 0; k < NQ; ++k) {
+                const uint4 a = s_q[NQ * tid + k];
                 qn = __builtin_amdgcn_udot4(a.x, a.x, qn, false); qn = __builtin_amdgcn_udot4(a.y, a.y, qn, false);
                 qn = __builtin_amdgcn_udot4(a.z, a.z, qn, false); qn = __builtin_amdgcn_udot4(a.w, a.w, qn, false);
             }
@@ -194,13 +231,21 @@ __global__ __launch_bounds__(256) void match_l2_nearest_kernel(const uint8_t *__
         }
         __syncthreads();
         for (int i = 0; i < nq; ++i) {
-            const unsigned ab = dot128_u8(s_q + 8 * i, t);
+            const unsigned ab = dot_u8<NQ>(s_q + NQ * i, t);
             const float d = sqrtf((float)(s_qn[i] + tn - 2u * ab));
-            if (d < bestd) { bestd = d; besti = qt + i; }
+            if (!RATIO) { if (d < bestd) { bestd = d; besti = qt + i; } }
+            else {
+                if (d < bestd) { second = bestd; bestd = d; besti = qt + i; }
+                else if (d < second) second = d;
+            }
         }
     }
-    if (valid && besti >= 0)
-        atomicMin(&best[(long long)pair * kcap + besti], ((unsigned long long)__float_as_uint(bestd) << 18) | (unsigned long long)j);
+    if (!RATIO) {
+        if (valid && besti >= 0)
+            atomicMin(&best[(long long)pair * kcap + besti], ((unsigned long long)__float_as_uint(bestd) << 18) | (unsigned long long)j);
+    } else if (valid && n_scan >= 2 && (double)bestd < ratio * (double)second) {
+        best[(long long)pair * kcap + j] = ((unsigned long long)__float_as_uint(bestd) << 18) | (unsigned long long)besti;
+    }
 }
 
 // Kernel 2: workgroup = pair: stable sort of the elected (distance, queryIdx) keys, first max_matches, point gather.
@@ -260,8 +305,13 @@ void rpe_launch_match_l2(rpe_handle *h, int B)
     const int kcap = h->lay.kcap;
     const int img2_base = h->img2_base ? h->img2_base : B;
     hipMemsetAsync(h->d_m_best, 0xFF, sizeof(unsigned long long) * (size_t)B * kcap, h->stream);
-    hipLaunchKernelGGL(match_l2_nearest_kernel, dim3((kcap + 255) / 256, B), dim3(256), 0, h->stream,
-                       h->d_desc, h->d_kp_count, img2_base, kcap, h->d_m_best);
+    const bool rt = h->cfg.match_mode == RPE_MATCH_RATIO;
+    const dim3 grid((kcap + 255) / 256, B);
+#define L2_LAUNCH(NQ, RT) hipLaunchKernelGGL((match_l2_nearest_kernel<NQ, RT>), grid, dim3(256), 0, h->stream, \
+                                             h->d_desc, h->d_kp_count, img2_base, kcap, h->cfg.match_ratio, h->d_m_best)
+    if (h->desc_bytes == 128) { if (rt) L2_LAUNCH(8, true); else L2_LAUNCH(8, false); }
+    else                      { if (rt) L2_LAUNCH(2, true); else L2_LAUNCH(2, false); }
+#undef L2_LAUNCH
     int sortP = 64;
     while (sortP < kcap) sortP <<= 1;
     hipLaunchKernelGGL(match_l2_select_kernel, dim3(B), dim3(256), sizeof(unsigned long long) * (size_t)sortP, h->stream,

@@ -161,16 +161,22 @@ static constexpr int CIRC_DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -
 static constexpr int CIRC_DY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
 
 #define FS_ROWS 66          // score rows / columns region (y0-1 .. y0+64)
-__global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ nms,
-                                                        unsigned *__restrict__ hist, RpeDeviceLayout lay,
+// Output: one compact list per tile of the keypoints that survive NMS and the border filter, packed
+// score << 24 | y << 12 | x (level coordinates), plus the per-(image, level) score histogram.  A strict 3x3
+// maximum cannot have an 8-neighbour that is one too, so a 64x64 tile holds at most 32*32 = 1024 of them:
+// RPE_FAST_TILE_CAP is never exceeded and nothing is ever dropped here.  ~0.5 % of the pixels survive, so
+// the lists replace a dense NMS map (1.6 MB written + re-read per VGA image) by ~100 bytes per tile; list
+// order inside a tile depends on wave timing, which nothing downstream reads (select ranks by (y, x)).
+__global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict__ pyr, unsigned *__restrict__ tile_list,
+                                                        int *__restrict__ tile_cnt, unsigned *__restrict__ hist, RpeDeviceLayout lay,
                                                         const RpeTile *__restrict__ tiles, int ntiles)
 {
     __shared__ unsigned s_in[72 * 18];              // pixels  y0-4 .. y0+67, x0-4 .. x0+67
     __shared__ __attribute__((aligned(16))) unsigned s_sc[FS_ROWS * 18];   // scores  y0-1 .. y0+64, x0-4 .. x0+67
-    __shared__ __attribute__((aligned(16))) unsigned s_nms[64 * 16];       // output tile
+    __shared__ __attribute__((aligned(16))) unsigned s_out[RPE_FAST_TILE_CAP];   // the tile's keypoint list
     __shared__ unsigned short s_cand[FS_ROWS * 72];
     __shared__ unsigned s_hist[256];
-    __shared__ int s_ncand;
+    __shared__ int s_ncand, s_nout;
     const int tid = threadIdx.x, lane = tid & 63;
     const int ti = xcd_tile(blockIdx.x, ntiles);
     if (ti >= ntiles) return;
@@ -179,20 +185,16 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
     const int w = L.w, hgt = L.h, pitch = L.pitch, thr = lay.fast_thr;
     const int x0 = t.tx, y0 = t.ty;
     const long long ibase = (long long)blockIdx.y * lay.stride + L.off;
-    const int tx = tid & 15, tyb = tid >> 4;
-    // tiles that cannot contain a keypoint after the border filter: write zeros only
+    const long long tslot = (long long)blockIdx.y * ntiles + ti;
+    // tiles that cannot contain a keypoint after the border filter (the host table lists none): empty list
     const bool live = w > 2 * RPE_EDGE && hgt > 2 * RPE_EDGE && x0 < w - RPE_EDGE && x0 + 64 > RPE_EDGE &&
                       y0 < hgt - RPE_EDGE && y0 + 64 > RPE_EDGE;
     if (!live) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            int px = x0 + 4 * tx, py = y0 + tyb + 16 * rr;
-            if (py < hgt && px < pitch) *(unsigned *)(nms + ibase + (long long)py * pitch + px) = 0u;
-        }
+        if (tid == 0) tile_cnt[tslot] = 0;
         return;
     }
     const uint8_t *src = pyr + ibase;
-    if (tid == 0) s_ncand = 0;
+    if (tid == 0) { s_ncand = 0; s_nout = 0; }
     s_hist[tid] = 0;
     {   // all tile loads in flight before the first LDS store.  lane -> fixed dword column (tid % 18) and rows
         // tid / 18 + 14 q: one column clamp and one division per tile instead of one per load
@@ -208,11 +210,10 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
 #pragma unroll
         for (int q = 0; q < 6; ++q) { const int r = lr + 14 * q; if (tid < 252 && r < 72) s_in[r * 18 + lc] = stage[q]; }
     }
-    {   // zero the score tile and the output tile with 16-B LDS stores
-        uint4 *z1 = (uint4 *)s_sc, *z2 = (uint4 *)s_nms;
+    {   // zero the score tile with 16-B LDS stores
+        uint4 *z1 = (uint4 *)s_sc;
         const uint4 z = make_uint4(0, 0, 0, 0);
         for (int i = tid; i < FS_ROWS * 18 / 4; i += 256) z1[i] = z;
-        z2[tid] = z;                                               // 64 * 16 dwords = 256 x 16 B
     }
     __syncthreads();
     // ---- phase 1 (packed 16-bit SWAR: even / odd pixels of the dword group in one VGPR each)
@@ -318,28 +319,40 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
         if (s > thr) ((uint8_t *)s_sc)[ry * 72 + bx] = (uint8_t)(s - 1);
     }
     __syncthreads();
-    // ---- phase 3: NMS + border filter + histogram, again over the candidate list
-    // (only pixels that went through phase 2 can hold a score)
+    // ---- phase 3: NMS + border filter + histogram over the candidate list (only pixels that went through
+    // phase 2 can hold a score); survivors are appended to the tile's list, one LDS atomic per wave and round
     const uint8_t *sc = (const uint8_t *)s_sc;
-    for (int i = tid; i < ncand; i += 256) {
-        const int cc = s_cand[i];
-        const int bx = cc & 127, ry = cc >> 7;
-        const int px = x0 - 4 + bx, py = y0 - 1 + ry;
-        if (bx < 4 || bx >= 68 || ry < 1 || ry > 64) continue;                       // halo pixels are not outputs
-        if (px < RPE_EDGE || px >= w - RPE_EDGE || py < RPE_EDGE || py >= hgt - RPE_EDGE) continue;
-        const uint8_t *q = sc + ry * 72 + bx;
-        const int v = q[0];
-        if (v == 0) continue;
-        const bool keep = v > q[-1] && v > q[1] && v > q[-73] && v > q[-72] && v > q[-71] && v > q[71] && v > q[72] && v > q[73];
-        if (keep) { ((uint8_t *)s_nms)[(ry - 1) * 64 + (bx - 4)] = (uint8_t)v; atomicAdd(&s_hist[v], 1u); }
+    for (int i0 = 0; i0 < ncand; i0 += 256) {                  // block-uniform trip count: the ballot sees whole waves
+        const int i = i0 + tid;
+        bool keep = false;
+        unsigned ent = 0;
+        if (i < ncand) {
+            const int cc = s_cand[i];
+            const int bx = cc & 127, ry = cc >> 7;
+            const int px = x0 - 4 + bx, py = y0 - 1 + ry;
+            const bool inside = bx >= 4 && bx < 68 && ry >= 1 && ry <= 64 &&                      // halo pixels are not outputs
+                                px >= RPE_EDGE && px < w - RPE_EDGE && py >= RPE_EDGE && py < hgt - RPE_EDGE;
+            const uint8_t *q = sc + ry * 72 + bx;
+            const int v = q[0];
+            if (inside && v != 0 && v > q[-1] && v > q[1] && v > q[-73] && v > q[-72] && v > q[-71] && v > q[71] && v > q[72] && v > q[73]) {
+                keep = true;
+                ent = ((unsigned)v << 24) | ((unsigned)py << 12) | (unsigned)px;
+                atomicAdd(&s_hist[v], 1u);
+            }
+        }
+        const unsigned long long km = __ballot(keep);
+        if (km) {                                              // wave-uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_nout, __popcll(km));
+            base = __shfl(base, 0);
+            if (keep) s_out[base + __popcll(km & ((1ull << lane) - 1ull))] = ent;
+        }
     }
     __syncthreads();
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int ty = tyb + 16 * rr;
-        const int px = x0 + 4 * tx, py = y0 + ty;
-        if (py < hgt && px < pitch) *(unsigned *)(nms + ibase + (long long)py * pitch + px) = s_nms[ty * 16 + tx];
-    }
+    const int nout = s_nout;                                   // <= RPE_FAST_TILE_CAP by the NMS argument above
+    unsigned *dst = tile_list + tslot * RPE_FAST_TILE_CAP;
+    for (int i = tid; i < nout; i += 256) dst[i] = s_out[i];
+    if (tid == 0) tile_cnt[tslot] = nout;
     const unsigned hc = s_hist[tid];
     if (hc) atomicAdd(&hist[((long long)blockIdx.y * RPE_NLEVELS + t.level) * 256 + tid], hc);
 }
@@ -347,11 +360,10 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
 void rpe_launch_fast(rpe_handle *h, int n_img)
 {
     hipMemsetAsync(h->d_hist, 0, sizeof(unsigned) * 256 * RPE_NLEVELS * (size_t)n_img, h->stream);
-    // tiles cover the border-filtered region only; the rest of the NMS map was zeroed at handle
-    // creation and is never written
+    // tiles cover the border-filtered region only
     if (h->n_tiles_fast == 0) return;
     hipLaunchKernelGGL(fast_nms_kernel, dim3((h->n_tiles_fast + 7) / 8 * 8, n_img), dim3(256), 0, h->stream,
-                       h->d_pyr, h->d_bufB, h->d_hist, h->lay, h->d_tiles_fast, h->n_tiles_fast);
+                       h->d_pyr, h->d_tile_list, h->d_tile_cnt, h->d_hist, h->lay, h->d_tiles_fast, h->n_tiles_fast);
 }
 
 void rpe_launch_nms(rpe_handle *h, int n_img) { (void)h; (void)n_img; }   // fused into fast_nms_kernel
@@ -374,18 +386,32 @@ __device__ __forceinline__ int block_excl_scan(int v, int *s_wave /*[5]*/, int &
 }
 
 // ----------------------------------------------------------------- select
-// KeyPointsFilter::retainBest(2*quota) on the FAST score: threshold = score of
-// the (2q)-th best keypoint, ties kept.  One workgroup per (image, level) scans
-// the NMS map linearly (raster order) and compacts survivors in that order.
-__global__ __launch_bounds__(256) void select_candidates_kernel(const uint8_t *__restrict__ nms, const unsigned *__restrict__ hist,
+// KeyPointsFilter::retainBest(2*quota) on the FAST score: threshold tau = score of the (2q)-th best
+// keypoint, ties kept.  One workgroup per (image, level) reads the level's tile lists (twice; the second
+// pass hits L2) and emits the survivors in RASTER order (y, then x) -- the canonical order the oracle uses --
+// by a counting sort over rows in LDS:
+//   pass 1  per-row count of the entries with score >= tau (LDS atomics)       -> exclusive scan = row starts
+//   pass 2  entry -> slot row_start[y] + (arrival order inside the row); rows that start at or beyond the
+//           candidate capacity are dropped here (their ranks are >= ccap whatever their x)
+//   pass 3  rank inside the row by x (a row holds a handful of entries) -> final position; positions >= ccap
+//           are truncated exactly as the oracle truncates (first ccap in raster order) and flagged.
+// Arrival order inside a row depends on wave timing; the final position does not.
+__global__ __launch_bounds__(256) void select_candidates_kernel(const unsigned *__restrict__ tile_list, const int *__restrict__ tile_cnt,
+                                                                 const unsigned *__restrict__ hist,
                                                                  unsigned *__restrict__ cand_xy, int *__restrict__ cand_count,
-                                                                 RpeDeviceLayout lay)
+                                                                 unsigned *__restrict__ ovf, RpeDeviceLayout lay, int ntiles, int rows_cap, int key_cap)
 {
+    extern __shared__ unsigned s_dyn[];
+    unsigned *s_rs = s_dyn;                          // [rows_cap + 1] per-row counts, then exclusive row starts
+    unsigned *s_fill = s_rs + rows_cap + 1;          // [rows_cap] arrival counters
+    unsigned *s_key = s_fill + rows_cap;             // [key_cap] staged y << 16 | x, grouped by row
+    unsigned *s_toff = s_key + key_cap;              // [level tiles + 1] exclusive prefix of the tile counts
     __shared__ int s_wave[5];
-    __shared__ int s_tau;
+    __shared__ int s_tau, s_live;
     const int tid = threadIdx.x, l = blockIdx.x, img = blockIdx.y;
     const RpeLevel &L = lay.lv[l];
     const unsigned *hg = hist + ((long long)img * RPE_NLEVELS + l) * 256;
+    if (tid == 64) s_live = 0x7FFFFFFF;
     if (tid < 64) {
         // wave 0: suffix sums over 256 bins, 4 bins per lane (descending)
         int b0 = 255 - 4 * tid;
@@ -407,70 +433,98 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const uint8_t *_
         int t = __shfl(tau, src_lane);
         if (tid == 0) s_tau = (total > n2 && m) ? max(t, 1) : 1;
     }
-    __syncthreads();
-    const int tau = s_tau;
-    // rows [31, h-31) only: the border band of the NMS map is zero by construction
-    const int row0 = (L.h > 2 * RPE_EDGE) ? RPE_EDGE : 0;
-    const uint8_t *src = nms + (long long)img * lay.stride + L.off + row0 * L.pitch;
-    const int nbytes = L.pitch * (L.h - 2 * row0);
-    const int ccap = L.ccap;
-    unsigned *out = cand_xy + (long long)img * lay.cand_total + L.cand_off;
-    int base = 0;
-    // 64 consecutive bytes per lane and step (4 x 16-B loads in flight): a quarter of the
-    // dependent HBM round trips / block scans of a 16-B-per-lane scan, same raster order
-    for (int c0 = 0; c0 < nbytes; c0 += 16384) {
-        const int pos = c0 + tid * 64;
-        uint4 v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            v[q] = make_uint4(0, 0, 0, 0);
-            if (pos + 16 * q < nbytes) v[q] = *(const uint4 *)(src + pos + 16 * q);
-        }
-        // byte >= tau for four bytes at a time (SWAR): with H = 0x80 per byte, ((x | H) - (T & ~H)) has bit 7 set where the
-        // low 7 bits compare >=, and the top bits decide otherwise; the flags stay at the byte MSBs, v_bcnt counts them
-        unsigned ge[16];
-        int cnt = 0;
-        {
-            const unsigned H = 0x80808080u, T = (unsigned)tau * 0x01010101u, Tl = T & ~H, nT = ~T;
-#pragma unroll
-            for (int d = 0; d < 16; ++d) {
-                const unsigned x = d < 4 ? (&v[0].x)[d] : d < 8 ? (&v[1].x)[d - 4] : d < 12 ? (&v[2].x)[d - 8] : (&v[3].x)[d - 12];
-                const unsigned lowge = (x | H) - Tl;
-                ge[d] = ((x & nT) | (~(x ^ T) & lowge)) & H;
-                cnt += __popc(ge[d]);
-            }
-        }
+    const int nrows = L.h, nt = L.ntile, ccap = L.ccap;
+    for (int i = tid; i <= nrows; i += 256) s_rs[i] = 0;
+    for (int i = tid; i < nrows; i += 256) s_fill[i] = 0;
+    // exclusive prefix of the level's tile counts (<= 16 tiles per lane and round)
+    const int *tc = tile_cnt + (long long)img * ntiles + L.tile0;
+    const unsigned *tl = tile_list + ((long long)img * ntiles + L.tile0) * RPE_FAST_TILE_CAP;
+    int nraw = 0;
+    for (int t0 = 0; t0 < nt; t0 += 256) {                 // block-uniform
+        const int t = t0 + tid;
+        const int c = t < nt ? tc[t] : 0;
         int total;
-        int ex = block_excl_scan(cnt, s_wave, total);
-        if (total) {                                               // block-uniform
-            int o = base + ex;
-            const int y0p = pos / L.pitch, x0p = pos - y0p * L.pitch;     // one division per lane, not one per byte
+        const int ex = block_excl_scan(c, s_wave, total);
+        if (t < nt) s_toff[t] = (unsigned)(nraw + ex);
+        nraw += total;
+    }
+    if (tid == 0) s_toff[nt] = (unsigned)nraw;
+    __syncthreads();
+    const unsigned tau = (unsigned)s_tau;
+    // entry s of the concatenated lists -> (tile, index) by binary search over the prefix
+    auto fetch = [&](int sidx) -> unsigned {
+        int lo = 0, hi = nt;                               // s_toff[lo] <= sidx < s_toff[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_toff[mid] <= (unsigned)sidx) lo = mid; else hi = mid; }
+        return tl[(long long)lo * RPE_FAST_TILE_CAP + (sidx - (int)s_toff[lo])];
+    };
+    for (int sidx = tid; sidx < nraw; sidx += 256) {
+        const unsigned e = fetch(sidx);
+        if ((e >> 24) >= tau) atomicAdd(&s_rs[(e >> 12) & 0xFFFu], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the row counts, 16 consecutive rows per lane
+    int kept = 0;
+    for (int r0 = 0; r0 < nrows; r0 += 4096) {             // block-uniform (one round: h <= 4095)
+        const int rb = r0 + tid * 16;
+        unsigned c[16]; int sum = 0;
 #pragma unroll
-            for (int d = 0; d < 16; ++d) {
-                if (__ballot(ge[d] != 0) == 0) continue;          // no lane of the wave has a hit in this dword (~half of them)
-                unsigned g = ge[d];
-                while (g) {
-                    const int k = 4 * d + ((__ffs((int)g) - 1) >> 3);      // byte index inside the 64
-                    g &= g - 1;
-                    if (o < ccap) {
-                        int x = x0p + k, y = y0p;                  // 64 bytes cross at most two row ends (pitch >= 48)
-                        if (x >= L.pitch) { x -= L.pitch; ++y; }
-                        if (x >= L.pitch) { x -= L.pitch; ++y; }
-                        out[o] = ((unsigned)(y + row0) << 16) | (unsigned)x;
-                    }
-                    ++o;
-                }
+        for (int k = 0; k < 16; ++k) { c[k] = (rb + k < nrows) ? s_rs[rb + k] : 0u; sum += (int)c[k]; }
+        int total;
+        int ex = block_excl_scan(sum, s_wave, total) + kept;
+        int first_out = 0x7FFFFFFF;                        // first row start at or beyond the capacity
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (rb + k < nrows) { s_rs[rb + k] = (unsigned)ex; if (ex >= ccap) first_out = min(first_out, ex); }
+            ex += (int)c[k];
+        }
+        if (first_out != 0x7FFFFFFF) atomicMin(&s_live, first_out);
+        kept += total;
+    }
+    if (tid == 0) s_rs[nrows] = (unsigned)kept;
+    __syncthreads();
+    for (int sidx = tid; sidx < nraw; sidx += 256) {
+        const unsigned e = fetch(sidx);
+        if ((e >> 24) >= tau) {
+            const unsigned y = (e >> 12) & 0xFFFu, rs = s_rs[y];
+            if (rs < (unsigned)ccap) {
+                const unsigned slot = rs + atomicAdd(&s_fill[y], 1u);
+                if (slot < (unsigned)key_cap) s_key[slot] = (y << 16) | (e & 0xFFFu);
             }
         }
-        base += total;
     }
-    if (tid == 0) cand_count[img * RPE_NLEVELS + l] = min(base, ccap);
+    __syncthreads();
+    unsigned *out = cand_xy + (long long)img * lay.cand_total + L.cand_off;
+    // staged slots: every row that starts below ccap is staged whole, so the live slots are [0, first row start >= ccap)
+    // (or all `kept` of them); a row holds <= w/2 keypoints, hence nlive <= ccap + w/2 <= key_cap
+    const int nlive = min(min(s_live, kept), key_cap);
+    for (int slot = tid; slot < nlive; slot += 256) {
+        const unsigned key = s_key[slot];
+        const unsigned y = key >> 16, x = key & 0xFFFFu;
+        const unsigned rs = s_rs[y], re = s_rs[y + 1];
+        unsigned rank = 0;
+        for (unsigned j = rs; j < re; ++j) rank += ((s_key[j] & 0xFFFFu) < x) ? 1u : 0u;
+        const unsigned pos = rs + rank;
+        if (pos < (unsigned)ccap) out[pos] = key;
+    }
+    if (tid == 0) {
+        cand_count[img * RPE_NLEVELS + l] = min(kept, ccap);
+        if (kept > ccap) atomicOr(&ovf[img], (unsigned)RPE_OVF_ORB_CANDIDATES);
+    }
 }
 
 void rpe_launch_select(rpe_handle *h, int n_img)
 {
-    hipLaunchKernelGGL(select_candidates_kernel, dim3(RPE_NLEVELS, n_img), dim3(256), 0, h->stream,
-                       h->d_bufB, h->d_hist, h->d_cand_xy, h->d_cand_count, h->lay);
+    // LDS: row starts + fill counters + staged keys (capacity: largest ccap + one full row of keypoints) + tile prefix
+    int rows_cap = 0, ccap_max = 0, nt_max = 0, wmax = 0;
+    for (int l = 0; l < RPE_NLEVELS; ++l) {
+        rows_cap = std::max(rows_cap, h->lay.lv[l].h); ccap_max = std::max(ccap_max, h->lay.lv[l].ccap);
+        nt_max = std::max(nt_max, h->lay.lv[l].ntile); wmax = std::max(wmax, h->lay.lv[l].w);
+    }
+    const int key_cap = ccap_max + wmax / 2 + 64;
+    const size_t lds = sizeof(unsigned) * ((size_t)rows_cap + 1 + rows_cap + key_cap + nt_max + 1);
+    hipLaunchKernelGGL(select_candidates_kernel, dim3(RPE_NLEVELS, n_img), dim3(256), lds, h->stream,
+                       (const unsigned *)h->d_tile_list, (const int *)h->d_tile_cnt, (const unsigned *)h->d_hist,
+                       h->d_cand_xy, h->d_cand_count, h->d_ovf, h->lay, h->n_tiles_fast, rows_cap, key_cap);
 }
 
 // ----------------------------------------------------------------- harris
@@ -550,7 +604,7 @@ __global__ __launch_bounds__(64 * RPE_NLEVELS) void select_keypoints_kernel(cons
                                                                              const int *__restrict__ cand_count,
                                                                              unsigned *__restrict__ kp_xy, float *__restrict__ kp_resp,
                                                                              float2 *__restrict__ kp_pt, int *__restrict__ kp_count,
-                                                                             RpeDeviceLayout lay)
+                                                                             unsigned *__restrict__ ovf, RpeDeviceLayout lay)
 {
     __shared__ unsigned s_hist[RPE_NLEVELS][256];
     __shared__ int s_cnt[RPE_NLEVELS];
@@ -624,14 +678,17 @@ __global__ __launch_bounds__(64 * RPE_NLEVELS) void select_keypoints_kernel(cons
         }
         offset += __popcll(km);
     }
-    if (threadIdx.x == 0) kp_count[img] = min(total, kcap);
+    if (threadIdx.x == 0) {
+        kp_count[img] = min(total, kcap);
+        if (total > kcap) atomicOr(&ovf[img], (unsigned)RPE_OVF_ORB_KEYPOINTS);
+    }
 }
 
 void rpe_launch_keypoints(rpe_handle *h, int n_img)
 {
     hipLaunchKernelGGL(select_keypoints_kernel, dim3(n_img), dim3(64 * RPE_NLEVELS), 0, h->stream,
                        h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_pt,
-                       h->d_kp_count, h->lay);
+                       h->d_kp_count, h->d_ovf, h->lay);
 }
 
 // ------------------------------------------------- orientation + descriptor
@@ -777,7 +834,7 @@ void rpe_launch_angle(rpe_handle *h, int n_img)
 __device__ __forceinline__ int refl101(int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * n - 2 - p : p; }
 
 __global__ __launch_bounds__(256) void blur_kernel(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ dst,
-                                                    RpeDeviceLayout lay, const RpeTile *__restrict__ tiles)
+                                                    RpeDeviceLayout lay, const RpeTile *__restrict__ tiles, int src_img)
 {
     // 64x64 tile; input 70 rows x 72 bytes (x0-4 .. x0+67) loaded as aligned dwords; rows
     // are reflected at load time, the <=3 reflected columns per side are patched in LDS.
@@ -788,8 +845,8 @@ __global__ __launch_bounds__(256) void blur_kernel(const uint8_t *__restrict__ p
     const RpeLevel &L = lay.lv[t.level];
     const int w = L.w, hgt = L.h, pitch = L.pitch;
     const int x0 = t.tx, y0 = t.ty;
-    const long long ibase = (long long)blockIdx.y * lay.stride + L.off;
-    const uint8_t *src = pyr + ibase;
+    const long long ibase = (long long)blockIdx.y * lay.stride + L.off;                 // destination: image slot blockIdx.y
+    const uint8_t *src = pyr + (long long)(src_img + blockIdx.y) * lay.stride + L.off;
     for (int i = tid; i < (TH + 6) * 18; i += 256) {
         int r = i / 18, c = i - r * 18;
         int y = refl101(y0 - 3 + r, hgt);
@@ -842,10 +899,11 @@ __global__ __launch_bounds__(256) void blur_kernel(const uint8_t *__restrict__ p
     }
 }
 
-void rpe_launch_blur(rpe_handle *h, int n_img)
+// whole-level blur of ONE image of the last run into the one-image debug buffer (rpe_orb_debug_fetch which = 3)
+void rpe_launch_blur(rpe_handle *h, int img)
 {
-    hipLaunchKernelGGL(blur_kernel, dim3(h->n_tiles_full, n_img), dim3(256), 0, h->stream,
-                       h->d_pyr, h->d_bufA, h->lay, h->d_tiles_full);
+    hipLaunchKernelGGL(blur_kernel, dim3(h->n_tiles_full, 1), dim3(256), 0, h->stream,
+                       h->d_pyr, h->d_bufA, h->lay, h->d_tiles_full, img);
 }
 
 // --------------------------------------------------------------- describe

@@ -41,6 +41,8 @@ extern "C" void rpe_default_config(rpe_config *c)
     c->ransac_max_iters = 1000;
     c->ransac_prob = 0.999;                // pose_estimator.py:525
     c->ransac_threshold = 1.0;             // pose_estimator.py:526
+    c->match_mode = RPE_MATCH_CROSSCHECK;  // pose_estimator.py:131 crossCheck=True
+    c->match_ratio = 0.75;
 }
 
 extern "C" int rpe_device_count(void)
@@ -127,16 +129,18 @@ static int dmalloc(rpe_handle *h, T **p, size_t n)
 static int build_tables(rpe_handle *h)
 {
     const RpeDeviceLayout &L = h->lay;
-    // tiles
+    // tiles (also records each level's run of FAST tiles in the layout)
     std::vector<RpeTile> full, fast;
     for (int l = 0; l < RPE_NLEVELS; ++l) {
         const RpeLevel &v = L.lv[l];
         for (int y = 0; y < v.h; y += 64)
             for (int x = 0; x < v.pitch; x += 64) full.push_back({(short)l, (short)x, (short)y, 0});
+        h->lay.lv[l].tile0 = (int)fast.size();
         if (v.w > 2 * RPE_EDGE && v.h > 2 * RPE_EDGE)
             // keypoints survive the border filter on [31, w-31) x [31, h-31) only; x origin dword aligned
             for (int y = RPE_EDGE; y < v.h - RPE_EDGE; y += 64)
                 for (int x = RPE_EDGE & ~3; x < v.w - RPE_EDGE; x += 64) fast.push_back({(short)l, (short)x, (short)y, 0});
+        h->lay.lv[l].ntile = (int)fast.size() - h->lay.lv[l].tile0;
     }
     h->n_tiles_full = (int)full.size(); h->n_tiles_fast = (int)fast.size();
     DM(h, h->d_tiles_full, full.size());
@@ -254,17 +258,21 @@ static int alloc_workspace(rpe_handle *h)
     const RpeDeviceLayout &L = h->lay;
     const size_t NI = (size_t)h->n_img_cap, B = (size_t)h->cfg.max_batch, mm = (size_t)h->cfg.max_matches;
     const size_t NIo = h->cfg.feature_method == RPE_FEATURE_SIFT ? 1 : NI;   // ORB pyramid buffers are unused by SIFT handles
-    DM(h, h->d_pyr, NIo * L.stride); DM(h, h->d_bufA, NIo * L.stride); DM(h, h->d_bufB, NIo * L.stride);
-    HIPCHK(h, hipMemset(h->d_bufA, 0, NIo * L.stride));
-    HIPCHK(h, hipMemset(h->d_bufB, 0, NIo * L.stride));
+    DM(h, h->d_pyr, NIo * L.stride); DM(h, h->d_bufA, L.stride);
+    HIPCHK(h, hipMemset(h->d_bufA, 0, L.stride));
     HIPCHK(h, hipMemset(h->d_pyr, 0, NIo * L.stride));
+    const size_t ntf = h->n_tiles_fast > 0 ? (size_t)h->n_tiles_fast : 1;
+    DM(h, h->d_tile_cnt, NIo * ntf); DM(h, h->d_tile_list, NIo * ntf * RPE_FAST_TILE_CAP);
+    HIPCHK(h, hipMemset(h->d_tile_cnt, 0, NIo * ntf * sizeof(int)));
     const size_t img = (size_t)h->cfg.width * h->cfg.height;
-    DM(h, h->d_stage1, B * img); DM(h, h->d_stage2, B * img);
+    DM(h, h->d_stage1, (B + 1) * img); DM(h, h->d_stage2, B * img);   // +1: a stream of max_batch pairs has max_batch + 1 frames
     DM(h, h->d_hist, NI * RPE_NLEVELS * 256);
     DM(h, h->d_cand_xy, NI * L.cand_total); DM(h, h->d_cand_resp, NI * L.cand_total);
     DM(h, h->d_cand_count, NI * RPE_NLEVELS);
     DM(h, h->d_kp_xy, NI * L.kcap); DM(h, h->d_kp_resp, NI * L.kcap); DM(h, h->d_kp_angle, NI * L.kcap);
     DM(h, h->d_kp_pt, NI * L.kcap); DM(h, h->d_kp_cs, NI * L.kcap); DM(h, h->d_kp_count, NI);
+    DM(h, h->d_ovf, NI);
+    HIPCHK(h, hipMemset(h->d_ovf, 0, NI * sizeof(unsigned)));
     DM(h, h->d_desc, NI * L.kcap * h->desc_bytes);
     HIPCHK(h, hipMemset(h->d_kp_pt, 0, NI * L.kcap * sizeof(float2)));
     HIPCHK(h, hipMemset(h->d_kp_count, 0, NI * sizeof(int)));
@@ -290,15 +298,19 @@ extern "C" int rpe_create(const rpe_config *cfg, rpe_handle **out)
     *out = nullptr;
     if (cfg->abi_version != RPE_ABI_VERSION) { g_create_err = "ABI version mismatch"; return RPE_ERR_INVALID; }
     const bool is_sift = cfg->feature_method == RPE_FEATURE_SIFT;
-    if (!((cfg->feature_method == RPE_FEATURE_ORB && cfg->norm_type == RPE_NORM_HAMMING) ||
-          (is_sift && cfg->norm_type == RPE_NORM_L2))) {
-        g_create_err = "supported combinations: ORB + Hamming, SIFT + L2"; return RPE_ERR_INVALID;
+    if (cfg->feature_method != RPE_FEATURE_ORB && !is_sift) { g_create_err = "unknown feature method"; return RPE_ERR_INVALID; }
+    if (cfg->norm_type != RPE_NORM_HAMMING && cfg->norm_type != RPE_NORM_L2) { g_create_err = "unknown norm type"; return RPE_ERR_INVALID; }
+    if (is_sift && cfg->norm_type == RPE_NORM_HAMMING) {
+        // cv2 builds this matcher but its match() rejects float descriptors (batchDistance: NORM_HAMMING needs CV_8U)
+        g_create_err = "NORM_HAMMING needs 8-bit descriptors: SIFT descriptors are float (cv2 raises in match())"; return RPE_ERR_INVALID;
     }
+    if (cfg->match_mode != RPE_MATCH_CROSSCHECK && cfg->match_mode != RPE_MATCH_RATIO) { g_create_err = "unknown match mode"; return RPE_ERR_INVALID; }
+    if (cfg->match_mode == RPE_MATCH_RATIO && !(cfg->match_ratio > 0. && cfg->match_ratio <= 1.)) { g_create_err = "match_ratio must be in (0, 1]"; return RPE_ERR_INVALID; }
     if (is_sift && (cfg->nfeatures > 4032 || cfg->nfeatures < 1 || cfg->width > 4000 || cfg->height > 4000)) {
         g_create_err = "SIFT: nfeatures (keypoint cap) must be <= 4032 and the image <= 4000 px"; return RPE_ERR_INVALID;
     }
     if (cfg->width < 96 || cfg->height < 96 || cfg->width > 4095 || cfg->height > 4095 || cfg->max_batch < 1 ||
-        cfg->nfeatures < 1 || cfg->nfeatures > 8000 || cfg->max_matches < 5 || cfg->max_matches > 2048 ||
+        cfg->nfeatures < 1 || cfg->nfeatures > 8000 || cfg->max_matches < 5 || cfg->max_matches > cfg->nfeatures + 64 ||
         cfg->ransac_max_iters < 1 || cfg->ransac_max_iters > 4096 || cfg->fast_threshold < 1 || cfg->fast_threshold > 254) {
         g_create_err = "configuration out of supported range"; return RPE_ERR_INVALID;
     }
@@ -333,11 +345,11 @@ extern "C" void rpe_destroy(rpe_handle *h)
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     rpe_sift_destroy(h);
-    void *ptrs[] = {h->d_tiles_full, h->d_tiles_fast, h->d_coef, h->d_pyr, h->d_bufA, h->d_bufB, h->d_stage1, h->d_stage2,
+    void *ptrs[] = {h->d_tiles_full, h->d_tiles_fast, h->d_coef, h->d_pyr, h->d_bufA, h->d_tile_list, h->d_tile_cnt, h->d_stage1, h->d_stage2,
                     h->d_hist, h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_angle,
                     h->d_kp_pt, h->d_kp_cs, h->d_kp_count, h->d_desc, h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2,
                     h->d_subsets, h->d_nit_denom, h->d_nit_round, h->d_rstate, h->d_n1, h->d_n2, h->d_found, h->d_models, h->d_hyp, h->d_counts,
-                    h->d_nmodels, h->d_mask, h->d_R, h->d_t, h->d_E, h->d_inliers, h->d_status, h->d_K, h->d_m_best};
+                    h->d_nmodels, h->d_mask, h->d_R, h->d_t, h->d_E, h->d_inliers, h->d_status, h->d_K, h->d_m_best, h->d_ovf};
     for (void *p : ptrs) if (p) hipFree(p);
     for (void *p : h->user_allocs) hipFree(p);
     for (int i = 0; i <= RPE_STAGE_COUNT; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
@@ -413,10 +425,11 @@ static int load_level0_fast(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_
     return RPE_OK;
 }
 
-static int run_orb(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, int nb, bool debug_blur = false)
+static int run_orb(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, int nb)
 {
     const int n = na + nb;
     MARK(h, RPE_STAGE_PYRAMID);
+    HIPCHK(h, hipMemsetAsync(h->d_ovf, 0, sizeof(unsigned) * (size_t)n, h->stream));
     int rc = load_level0_fast(h, d_a, d_b, na, nb);
     if (rc) return rc;
     rpe_launch_pyramid(h, n);
@@ -426,7 +439,7 @@ static int run_orb(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na
     MARK(h, RPE_STAGE_HARRIS);    rpe_launch_harris(h, n);
     MARK(h, RPE_STAGE_KEYPOINTS); rpe_launch_keypoints(h, n);
     MARK(h, RPE_STAGE_ANGLE);     rpe_launch_angle(h, n);
-    MARK(h, RPE_STAGE_BLUR);      if (debug_blur) rpe_launch_blur(h, n);   // whole-level blur only for rpe_orb_debug_fetch
+    MARK(h, RPE_STAGE_BLUR);      // fused into the per-keypoint kernel (the whole-level blur runs on demand in rpe_orb_debug_fetch)
     MARK(h, RPE_STAGE_DESCRIBE);  rpe_launch_describe(h, n);
     MARK(h, RPE_STAGE_MATCH);
     HIPCHK(h, hipGetLastError());
@@ -439,29 +452,41 @@ static int set_K(rpe_handle *h, const double K[9])
     return RPE_OK;
 }
 
+// feature extraction + matching + geometry of `pairs` pairs whose images sit in slots (p, img2_base + p)
+static int run_pairs(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, int nb, int pairs, int img2_base)
+{
+    struct Guard {                          // the launchers read h->img2_base; never leave a stream's value behind
+        rpe_handle *h; ~Guard() { h->img2_base = 0; }
+    } guard{h};
+    h->img2_base = img2_base;
+    h->last_pairs = pairs; h->last_img2_base = img2_base;
+    h->last_chunked = false;
+    int rc;
+    if (h->cfg.feature_method == RPE_FEATURE_SIFT) {
+        if ((rc = rpe_sift_run(h, d_a, d_b, na, nb)) != RPE_OK) return rc;             // records PYRAMID .. DESCRIBE
+        MARK(h, RPE_STAGE_MATCH);
+    } else {
+        if ((rc = run_orb(h, d_a, d_b, na, nb)) != RPE_OK) return rc;
+    }
+    if (h->cfg.norm_type == RPE_NORM_L2) rpe_launch_match_l2(h, pairs);
+    else rpe_launch_match(h, pairs);
+    MARK(h, RPE_STAGE_RANSAC);
+    rpe_launch_ransac(h, pairs, false);
+    MARK(h, RPE_STAGE_POSE);
+    rpe_launch_pose(h, pairs, true);
+    if (h->profiling) { hipEventRecord(h->ev[RPE_STAGE_COUNT], h->stream); h->ev_valid = true; }
+    HIPCHK(h, hipGetLastError());
+    return RPE_OK;
+}
+
 extern "C" int rpe_enqueue_batch_device(rpe_handle *h, const uint8_t *d_imgs1, const uint8_t *d_imgs2, int B, const double K[9])
 {
     if (!h || !d_imgs1 || !d_imgs2 || !K || B < 1) return RPE_ERR_INVALID;
     if (B > h->cfg.max_batch) { h->err = "batch exceeds max_batch"; return RPE_ERR_CAPACITY; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    h->last_chunked = false;
     int rc = set_K(h, K);
     if (rc) return rc;
-    if (h->cfg.feature_method == RPE_FEATURE_SIFT) {
-        if ((rc = rpe_sift_run(h, d_imgs1, d_imgs2, B, B)) != RPE_OK) return rc;       // records PYRAMID .. DESCRIBE
-        MARK(h, RPE_STAGE_MATCH);
-        rpe_launch_match_l2(h, B);
-    } else {
-        if ((rc = run_orb(h, d_imgs1, d_imgs2, B, B)) != RPE_OK) return rc;
-        rpe_launch_match(h, B);
-    }
-    MARK(h, RPE_STAGE_RANSAC);
-    rpe_launch_ransac(h, B, false);
-    MARK(h, RPE_STAGE_POSE);
-    rpe_launch_pose(h, B, true);
-    if (h->profiling) { hipEventRecord(h->ev[RPE_STAGE_COUNT], h->stream); h->ev_valid = true; }
-    HIPCHK(h, hipGetLastError());
-    return RPE_OK;
+    return run_pairs(h, d_imgs1, d_imgs2, B, B, B, B);
 }
 
 // Consecutive-frame stream (reference batch_processor.py:71-109): F frames -> F-1
@@ -474,23 +499,7 @@ extern "C" int rpe_enqueue_stream_device(rpe_handle *h, const uint8_t *d_frames,
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int rc = set_K(h, K);
     if (rc) return rc;
-    h->img2_base = 1;
-    if (h->cfg.feature_method == RPE_FEATURE_SIFT) {
-        if ((rc = rpe_sift_run(h, d_frames, d_frames, F, 0)) != RPE_OK) return rc;     // records PYRAMID .. DESCRIBE
-        MARK(h, RPE_STAGE_MATCH);
-        rpe_launch_match_l2(h, F - 1);
-    } else {
-        if ((rc = run_orb(h, d_frames, d_frames, F, 0)) != RPE_OK) return rc;
-        rpe_launch_match(h, F - 1);
-    }
-    MARK(h, RPE_STAGE_RANSAC);
-    rpe_launch_ransac(h, F - 1, false);
-    MARK(h, RPE_STAGE_POSE);
-    rpe_launch_pose(h, F - 1, true);
-    h->img2_base = 0;
-    if (h->profiling) { hipEventRecord(h->ev[RPE_STAGE_COUNT], h->stream); h->ev_valid = true; }
-    HIPCHK(h, hipGetLastError());
-    return RPE_OK;
+    return run_pairs(h, d_frames, d_frames, F, 0, F - 1, 1);
 }
 
 extern "C" int rpe_estimate_stream(rpe_handle *h, const uint8_t *h_frames, int F, const double K[9],
@@ -500,20 +509,10 @@ extern "C" int rpe_estimate_stream(rpe_handle *h, const uint8_t *h_frames, int F
     if (F > h->n_img_cap || F - 1 > h->cfg.max_batch) { h->err = "stream longer than the handle capacity (frames <= 2*max_batch, pairs <= max_batch)"; return RPE_ERR_CAPACITY; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const size_t img = (size_t)h->cfg.width * h->cfg.height;
-    // staging: frames are spread over the two staging buffers only if they do not fit the first
-    if ((size_t)F <= (size_t)h->cfg.max_batch) {
-        HIPCHK(h, hipMemcpyAsync(h->d_stage1, h_frames, img * F, hipMemcpyHostToDevice, h->stream));
-        int rc = rpe_enqueue_stream_device(h, h->d_stage1, F, K);
-        if (rc) return rc;
-    } else {
-        void *tmp = nullptr;
-        HIPCHK(h, hipMalloc(&tmp, img * F));
-        HIPCHK(h, hipMemcpyAsync(tmp, h_frames, img * F, hipMemcpyHostToDevice, h->stream));
-        int rc = rpe_enqueue_stream_device(h, (const uint8_t *)tmp, F, K);
-        hipStreamSynchronize(h->stream);
-        hipFree(tmp);
-        if (rc) return rc;
-    }
+    // d_stage1 holds max_batch + 1 frames: every legal stream fits the persistent staging buffer
+    HIPCHK(h, hipMemcpyAsync(h->d_stage1, h_frames, img * F, hipMemcpyHostToDevice, h->stream));
+    int rc = rpe_enqueue_stream_device(h, h->d_stage1, F, K);
+    if (rc) return rc;
     return rpe_fetch_results(h, F - 1, R, t, inliers, n_matches, status);
 }
 
@@ -591,6 +590,19 @@ extern "C" int rpe_fetch_results(rpe_handle *h, int B, double *R, double *t, int
     return RPE_OK;
 }
 
+extern "C" int rpe_fetch_overflow(rpe_handle *h, int n_pairs, uint32_t *flags)
+{
+    if (!h || !flags || n_pairs < 1 || n_pairs > h->cfg.max_batch) return RPE_ERR_INVALID;
+    if (h->last_chunked) { h->err = "the last host batch ran in chunks: capacity flags are kept for single-launch batches only"; return RPE_ERR_INVALID; }
+    if (n_pairs > h->last_pairs) { h->err = "rpe_fetch_overflow: more pairs than the last batch had"; return RPE_ERR_INVALID; }
+    const int nimg = h->last_img2_base + n_pairs;
+    std::vector<unsigned> ov((size_t)nimg);
+    HIPCHK(h, hipMemcpyAsync(ov.data(), h->d_ovf, sizeof(unsigned) * (size_t)nimg, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int p = 0; p < n_pairs; ++p) flags[p] = ov[p] | ov[h->last_img2_base + p];
+    return RPE_OK;
+}
+
 extern "C" int rpe_estimate_batch_device(rpe_handle *h, const uint8_t *d_imgs1, const uint8_t *d_imgs2, int B, const double K[9],
                                          double *R, double *t, int32_t *inliers, int32_t *n_matches, int32_t *status)
 {
@@ -606,7 +618,6 @@ extern "C" int rpe_estimate_batch(rpe_handle *h, const uint8_t *h_imgs1, const u
     if (B > h->cfg.max_batch) { h->err = "batch exceeds max_batch"; return RPE_ERR_CAPACITY; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const size_t img = (size_t)h->cfg.width * h->cfg.height;
-    h->last_chunked = false;
     // Large host batches run in chunks: all uploads are queued on a copy stream, chunk c's kernels wait for its
     // 'resident' event only, so the PCIe transfer of the later chunks hides behind the kernels of the earlier ones
     // (1024 VGA pairs: 629 MB = 12 ms of copy in front of 16 ms of kernels when done in one piece).
@@ -671,7 +682,7 @@ extern "C" int rpe_orb_detect_and_compute(rpe_handle *h, const uint8_t *h_imgs, 
     const int na = n_images < h->cfg.max_batch ? n_images : h->cfg.max_batch, nb = n_images - na;
     HIPCHK(h, hipMemcpyAsync(h->d_stage1, h_imgs, img * na, hipMemcpyHostToDevice, h->stream));
     if (nb) HIPCHK(h, hipMemcpyAsync(h->d_stage2, h_imgs + img * na, img * nb, hipMemcpyHostToDevice, h->stream));
-    int rc = run_orb(h, h->d_stage1, h->d_stage2, na, nb, true);
+    int rc = run_orb(h, h->d_stage1, h->d_stage2, na, nb);
     if (rc) return rc;
     const int kcap = h->lay.kcap;
     std::vector<unsigned> xy((size_t)n_images * kcap);
@@ -709,10 +720,35 @@ extern "C" int64_t rpe_orb_pyramid_pixels(const rpe_handle *h)
 extern "C" int rpe_orb_debug_fetch(rpe_handle *h, int index, int which, uint8_t *h_out)
 {
     if (!h || !h_out || index < 0 || index >= h->n_img_cap) return RPE_ERR_INVALID;
-    const uint8_t *src = which == 0 ? h->d_pyr : (which == 2 ? h->d_bufB : h->d_bufA);
-    std::vector<uint8_t> tmp((size_t)h->lay.stride);
-    HIPCHK(h, hipMemcpyAsync(tmp.data(), src + (size_t)index * h->lay.stride, tmp.size(), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->cfg.feature_method != RPE_FEATURE_ORB) { h->err = "rpe_orb_debug_fetch: handle was not created for ORB"; return RPE_ERR_INVALID; }
+    if (which != 0 && which != 2 && which != 3) { h->err = "rpe_orb_debug_fetch: which must be 0 (pyramid), 2 (NMS map) or 3 (blurred pyramid)"; return RPE_ERR_INVALID; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    std::vector<uint8_t> tmp((size_t)h->lay.stride, 0);
+    if (which == 2) {
+        // the NMS map is not materialised any more: rebuild it from the tile lists of the image
+        const size_t nt = (size_t)h->n_tiles_fast;
+        std::vector<int> cnt(nt ? nt : 1);
+        std::vector<unsigned> lst((nt ? nt : 1) * RPE_FAST_TILE_CAP);
+        if (nt) {
+            HIPCHK(h, hipMemcpyAsync(cnt.data(), h->d_tile_cnt + (size_t)index * nt, nt * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(lst.data(), h->d_tile_list + (size_t)index * nt * RPE_FAST_TILE_CAP, nt * RPE_FAST_TILE_CAP * sizeof(unsigned),
+                                     hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
+        for (int l = 0; l < RPE_NLEVELS; ++l) {
+            const RpeLevel &v = h->lay.lv[l];
+            for (int t = v.tile0; t < v.tile0 + v.ntile; ++t)
+                for (int k = 0; k < cnt[t] && k < RPE_FAST_TILE_CAP; ++k) {
+                    const unsigned e = lst[(size_t)t * RPE_FAST_TILE_CAP + k];
+                    tmp[v.off + (size_t)((e >> 12) & 0xFFF) * v.pitch + (e & 0xFFF)] = (uint8_t)(e >> 24);
+                }
+        }
+    } else {
+        const uint8_t *src = h->d_pyr + (size_t)index * h->lay.stride;
+        if (which == 3) { rpe_launch_blur(h, index); HIPCHK(h, hipGetLastError()); src = h->d_bufA; }
+        HIPCHK(h, hipMemcpyAsync(tmp.data(), src, tmp.size(), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     uint8_t *o = h_out;
     for (int l = 0; l < RPE_NLEVELS; ++l) {
         const RpeLevel &v = h->lay.lv[l];
@@ -813,46 +849,118 @@ extern "C" int rpe_get_stage_ms(rpe_handle *h, float *ms)
     return RPE_OK;
 }
 
-// ------------------------------------------------------- PMC calibration (debug)
-// Streams a known byte count with 4-B or 16-B per-lane loads so that rocprofv3's
-// FETCH_SIZE can be calibrated for this library's access widths (MI355X guide: gfx950
-// reports 1/2 of the bytes of 16-B/lane streams; other widths must be calibrated).
-__global__ __launch_bounds__(256) void calib_read4_kernel(const unsigned *__restrict__ p, size_t n, unsigned *sink)
+// ------------------------------------------------------------ roofline calibration
+// The hot path is bound by vector-instruction ISSUE, not by HBM, so bench.py prices the
+// dominant kernel and the matcher against a MEASURED issue rate: each kernel below runs a long stream of one
+// instruction kind (inline asm: the count is exact, nothing is folded away) over independent register chains,
+// at 1, 2, 4 or 8 resident waves per SIMD on every CU.  MI355X_MICROARCH.md: a wave64 VALU instruction takes
+// 2 cycles on the 32-wide SIMD when >= 2 waves feed it, 4 cycles for one wave alone; f64 and transcendental
+// instructions take longer.  Kinds: the instructions the ORB / matcher / RANSAC inner loops are made of.
+#define CALIB_UNROLL 16
+template <int KIND>
+__global__ __launch_bounds__(256) void valu_calib_kernel(unsigned *sink, int iters)
 {
+    unsigned a[8];
+    double d[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a[u] = threadIdx.x * 2654435761u + u * 40503u + blockIdx.x; d[u] = 1.0 + 1e-9 * (double)(a[u] & 1023u); }
+    const unsigned k0 = 0x9E3779B9u ^ threadIdx.x, k1 = 0x01010101u;
+    const double dk = 1.0000000001;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < CALIB_UNROLL / 8; ++r) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (KIND == 0)       // the Hamming inner loop: v_xor_b32 + v_bcnt_u32_b32 (2 instructions)
+                    asm volatile("v_xor_b32 %0, %0, %1\n\tv_bcnt_u32_b32 %0, %0, %2" : "+v"(a[u]) : "v"(k0), "v"(k1));
+                else if (KIND == 1)  // FAST pair test: packed 16-bit min / max (2 instructions)
+                    asm volatile("v_pk_min_i16 %0, %0, %1\n\tv_pk_max_i16 %0, %0, %2" : "+v"(a[u]) : "v"(k0), "v"(k1));
+                else if (KIND == 2)  // byte gather: v_perm_b32 (1 instruction)
+                    asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[u]) : "v"(k0), "v"(k1));
+                else if (KIND == 3)  // packed-u8 dot product: v_dot4_u32_u8 (1 instruction)
+                    asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(a[u]) : "v"(k0), "v"(k1));
+                else if (KIND == 4)  // FAST ring score: v_min3_i32 + v_max3_i32 (2 instructions)
+                    asm volatile("v_min3_i32 %0, %0, %1, %2\n\tv_max3_i32 %0, %0, %1, %2" : "+v"(a[u]) : "v"(k0), "v"(k1));
+                else if (KIND == 5)  // resize / blur taps: v_mad_u32_u24 (1 instruction)
+                    asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[u]) : "v"(k1), "v"(k0));
+                else if (KIND == 6)  // RANSAC / pose: v_mul_f64 + v_add_f64 (2 instructions; the library compiles without contraction)
+                    asm volatile("v_mul_f64 %0, %0, %1\n\tv_add_f64 %0, %0, %1" : "+v"(d[u]) : "v"(dk));
+                else                 // v_fma_f64 (1 instruction), for reference
+                    asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d[u]) : "v"(dk));
+            }
+        }
+    }
     unsigned acc = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc ^= p[i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc ^= a[u] ^ (unsigned)__double_as_longlong(d[u]);
     if (acc == 0x12345679u) *sink = acc;
 }
+
+static const int kCalibInstPerSlot[8] = {2, 2, 1, 1, 2, 1, 2, 1};
+static const char *kCalibNames[8] = {"v_xor_b32+v_bcnt_u32_b32", "v_pk_min_i16+v_pk_max_i16", "v_perm_b32", "v_dot4_u32_u8",
+                                     "v_min3_i32+v_max3_i32", "v_mad_u32_u24", "v_mul_f64+v_add_f64", "v_fma_f64"};
+extern "C" const char *rpe_calibrate_valu_name(int kind) { return (kind >= 0 && kind < 8) ? kCalibNames[kind] : "?"; }
+
+extern "C" int rpe_calibrate_valu(rpe_handle *h, int kind, int waves_per_simd, double *wave_insts_per_s)
+{
+    if (!h || !wave_insts_per_s || kind < 0 || kind > 7 || waves_per_simd < 1 || waves_per_simd > 8) return RPE_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, h->cfg.device));
+    const int ncu = prop.multiProcessorCount;
+    // one 256-thread block = 4 waves = one wave per SIMD of a CU; waves_per_simd blocks per CU
+    const int blocks = ncu * waves_per_simd, iters = 20000;
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {                    // first repetition warms up
+        HIPCHK(h, hipEventRecord(e0, h->stream));
+        switch (kind) {
+#define CALIB_CASE(K) case K: hipLaunchKernelGGL((valu_calib_kernel<K>), dim3(blocks), dim3(256), 0, h->stream, (unsigned *)h->d_hist, iters); break;
+            CALIB_CASE(0) CALIB_CASE(1) CALIB_CASE(2) CALIB_CASE(3) CALIB_CASE(4) CALIB_CASE(5) CALIB_CASE(6) CALIB_CASE(7)
+#undef CALIB_CASE
+        }
+        HIPCHK(h, hipEventRecord(e1, h->stream));
+        HIPCHK(h, hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    const double insts = (double)blocks * 4.0 * (double)iters * CALIB_UNROLL * kCalibInstPerSlot[kind];
+    *wave_insts_per_s = insts / ((double)best * 1e-3);
+    return RPE_OK;
+}
+
+// HBM streaming rate of this device: 16-B-per-lane read of the handle's pyramid buffer (>= 256 MiB so the
+// Infinity Cache cannot serve it) -- the "achievable" figure next to the 8 TB/s spec peak in the bench line.
 __global__ __launch_bounds__(256) void calib_read16_kernel(const uint4 *__restrict__ p, size_t n, unsigned *sink)
 {
     unsigned acc = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { uint4 v = p[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
     if (acc == 0x12345679u) *sink = acc;
 }
-// tile-shaped reads like the stencil kernels: 72-byte row segments, 72 rows, dword loads
-__global__ __launch_bounds__(256) void calib_tile_kernel(const uint8_t *__restrict__ p, int pitch, int rows, size_t img_stride, unsigned *sink)
+extern "C" int rpe_calibrate_hbm(rpe_handle *h, double *bytes_per_s)
 {
-    const uint8_t *src = p + (size_t)blockIdx.z * img_stride;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
-    unsigned acc = 0;
-    for (int i = threadIdx.x; i < 72 * 18; i += 256) {
-        int r = i / 18, c = i - r * 18;
-        int y = min(max(y0 - 4 + r, 0), rows - 1), x = min(max(x0 - 4 + 4 * c, 0), pitch - 4);
-        acc ^= *(const unsigned *)(src + (size_t)y * pitch + x);
+    if (!h || !bytes_per_s) return RPE_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t NIo = h->cfg.feature_method == RPE_FEATURE_SIFT ? 1 : (size_t)h->n_img_cap;
+    const size_t bytes = NIo * (size_t)h->lay.stride;
+    if (bytes < ((size_t)256 << 20)) { h->err = "rpe_calibrate_hbm: the handle's pyramid buffer is smaller than the 256 MiB Infinity Cache"; return RPE_ERR_INVALID; }
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        HIPCHK(h, hipEventRecord(e0, h->stream));
+        hipLaunchKernelGGL(calib_read16_kernel, dim3(8192), dim3(256), 0, h->stream, (const uint4 *)h->d_pyr, bytes / 16, (unsigned *)h->d_hist);
+        HIPCHK(h, hipEventRecord(e1, h->stream));
+        HIPCHK(h, hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
     }
-    if (acc == 0x12345679u) *sink = acc;
-}
-extern "C" int rpe_debug_calibrate(rpe_handle *h, long long *bytes_out)
-{
-    if (!h) return RPE_ERR_INVALID;
-    const size_t bytes = (size_t)h->n_img_cap * h->lay.stride;
-    hipLaunchKernelGGL(calib_read4_kernel, dim3(4096), dim3(256), 0, h->stream, (const unsigned *)h->d_bufA, bytes / 4, (unsigned *)h->d_hist);
-    hipLaunchKernelGGL(calib_read16_kernel, dim3(4096), dim3(256), 0, h->stream, (const uint4 *)h->d_bufB, bytes / 16, (unsigned *)h->d_hist);
-    const RpeLevel &v = h->lay.lv[0];
-    hipLaunchKernelGGL(calib_tile_kernel, dim3(v.pitch / 64, v.h / 64, h->n_img_cap), dim3(256), 0, h->stream,
-                       h->d_pyr, v.pitch, v.h, (size_t)h->lay.stride, (unsigned *)h->d_hist);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (bytes_out) { bytes_out[0] = (long long)bytes; bytes_out[1] = (long long)bytes; bytes_out[2] = (long long)(v.pitch / 64) * (v.h / 64) * 64 * 64 * h->n_img_cap; }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *bytes_per_s = (double)bytes / ((double)best * 1e-3);
     return RPE_OK;
 }
 
@@ -908,15 +1016,16 @@ extern "C" int rpe_match_l2(rpe_handle *h, const float *h_desc1, const int32_t *
     if (h->cfg.norm_type != RPE_NORM_L2) { h->err = "handle was not created for NORM_L2"; return RPE_ERR_INVALID; }
     if (B > h->cfg.max_batch) { h->err = "batch exceeds max_batch"; return RPE_ERR_CAPACITY; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    const size_t per = (size_t)h->lay.kcap * 128, mm = h->cfg.max_matches;
+    const size_t dim = (size_t)h->desc_bytes;               // 128 (SIFT) or 32 (ORB descriptors under NORM_L2)
+    const size_t per = (size_t)h->lay.kcap * dim, mm = h->cfg.max_matches;
     std::vector<uint8_t> u(2 * per * B, 0);
     for (int s = 0; s < 2; ++s) {
         const float *src = s ? h_desc2 : h_desc1; const int32_t *cn = s ? n2 : n1;
         for (int i = 0; i < B; ++i) {
             if (cn[i] < 0 || cn[i] > h->lay.kcap) { h->err = "descriptor count exceeds keypoint capacity"; return RPE_ERR_INVALID; }
-            for (size_t e = 0; e < (size_t)cn[i] * 128; ++e) {
+            for (size_t e = 0; e < (size_t)cn[i] * dim; ++e) {
                 float v = src[(size_t)i * per + e];
-                if (!(v >= 0.f && v <= 255.f) || v != (float)(int)v) { h->err = "NORM_L2 path expects SIFT descriptors (integer-valued 0..255)"; return RPE_ERR_INVALID; }
+                if (!(v >= 0.f && v <= 255.f) || v != (float)(int)v) { h->err = "NORM_L2 path expects byte-valued descriptors (SIFT's integer-valued 0..255 floats, or ORB bytes)"; return RPE_ERR_INVALID; }
                 u[(size_t)s * per * B + (size_t)i * per + e] = (uint8_t)v;
             }
         }

@@ -13,6 +13,7 @@
 #define RPE_RANSAC_CHUNK 64    // solver wave granularity: 64 RANSAC iterations per wave
 #define RPE_RANSAC_MAXCHUNK 512 // largest number of iterations evaluated per launch group (8 waves per pair)
 #define RPE_MAX_MODELS 10
+#define RPE_FAST_TILE_CAP 1024 // entries of one 64x64 FAST tile list = the most strict 3x3 maxima a tile can hold
 
 // ---- HBM layout of one image's pyramid-shaped buffers ---------------------
 // Level l is stored with row pitch align16(w_l) at byte offset off[l] (256-B
@@ -26,6 +27,7 @@ struct RpeLevel {
     float scale;      // (float)pow(1.1f, l)
     long long off;    // byte offset inside the per-image pyramid buffer
     int coef_off;     // offset of xo/xa (w entries) then yo/ya (h entries) in coef table
+    int tile0, ntile; // this level's run inside the FAST tile table (raster order inside the level)
 };
 
 struct RpeDeviceLayout {       // passed by value to kernels
@@ -72,7 +74,10 @@ struct rpe_handle {
     RpeTile *d_tiles_fast = nullptr;  int n_tiles_fast = 0;   // tiles covering [28,w-28)x[28,h-28)
     int *d_coef = nullptr;            // resize coefficient tables
     // image-shaped buffers
-    uint8_t *d_pyr = nullptr, *d_bufA = nullptr, *d_bufB = nullptr;
+    uint8_t *d_pyr = nullptr;
+    uint8_t *d_bufA = nullptr;        // ONE image's blurred pyramid (rpe_orb_debug_fetch only)
+    unsigned *d_tile_list = nullptr;  // [img][n_tiles_fast][RPE_FAST_TILE_CAP] score << 24 | y << 12 | x
+    int *d_tile_cnt = nullptr;        // [img][n_tiles_fast]
     uint8_t *d_stage1 = nullptr, *d_stage2 = nullptr; // staging for host-image API
     // detection
     unsigned *d_hist = nullptr;       // [img][level][256]
@@ -84,6 +89,8 @@ struct rpe_handle {
     float2 *d_kp_pt = nullptr;
     float2 *d_kp_cs = nullptr;        // [img][kcap] (cos, sin) of the keypoint angle
     int *d_kp_count = nullptr;        // [img]
+    unsigned *d_ovf = nullptr;        // [img] RPE_OVF_* capacity flags of the last extraction
+    int last_pairs = 0, last_img2_base = 0;   // image slots of the last batch's pairs: (p, last_img2_base + p)
     uint8_t *d_desc = nullptr;        // [img][kcap][32]
     // matching
     int *d_m_q = nullptr, *d_m_t = nullptr, *d_m_d = nullptr, *d_m_n = nullptr;
@@ -96,7 +103,7 @@ struct rpe_handle {
     double nit_num = 0;                   // log(1-p)
     RpeRansacState *d_rstate = nullptr;
     double2 *d_n1 = nullptr, *d_n2 = nullptr;   // K-normalised matched points [pair][max_matches]
-    int *d_found = nullptr;                   // [pair]
+    int *d_found = nullptr;                   // [pair] 0 none, 1 one model, n > 1: n stacked models (exactly 5 matches)
     double *d_hyp = nullptr;              // [pair][88][64] per-hypothesis record between the two solver kernels
     double *d_models = nullptr;           // [pair][CHUNK][10][9]
     int *d_nmodels = nullptr;             // [pair][MAXCHUNK]

@@ -368,7 +368,8 @@ __global__ __launch_bounds__(256) void sift_extrema_mask_kernel(const float *__r
 }
 
 // exclusive scan of the band counters of one image (256 threads, a run of consecutive bands each)
-__global__ __launch_bounds__(256) void sift_band_scan_kernel(const int *__restrict__ band_cnt, int *__restrict__ band_off, int *__restrict__ nseeds, SiftDev dv)
+__global__ __launch_bounds__(256) void sift_band_scan_kernel(const int *__restrict__ band_cnt, int *__restrict__ band_off, int *__restrict__ nseeds,
+                                                              unsigned *__restrict__ overflow, SiftDev dv)
 {
     __shared__ int s_wave[5];
     const int img = blockIdx.x, tid = threadIdx.x;
@@ -380,7 +381,10 @@ __global__ __launch_bounds__(256) void sift_band_scan_kernel(const int *__restri
     int acc = s_block_excl_scan(sum, s_wave, total);
     int *bo = band_off + (long long)img * dv.nbands;
     for (int b = b0; b < b1; ++b) { bo[b] = acc; acc += bc[b]; }
-    if (tid == 0) nseeds[img] = total < dv.seed_cap ? total : dv.seed_cap;
+    if (tid == 0) {
+        nseeds[img] = total < dv.seed_cap ? total : dv.seed_cap;
+        if (total > dv.seed_cap) atomicOr(&overflow[img], (unsigned)RPE_OVF_SIFT_SEEDS);
+    }
 }
 
 // Pass 2: one wave per band (row) walks the row's mask words in order and writes the seeds at the
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(256) void sift_adjust_kernel(const float *__restric
 
 __global__ __launch_bounds__(256) void sift_orient_kernel(const float *__restrict__ gauss, SiftDev dv,
                                                            const float *__restrict__ surv, const int *__restrict__ nsurv,
-                                                           float *__restrict__ raw, int *__restrict__ nraw, int *__restrict__ overflow)
+                                                           float *__restrict__ raw, int *__restrict__ nraw, unsigned *__restrict__ overflow)
 {
     __shared__ float s_part[4][S_BINS][8];
     __shared__ float s_hist[4][S_BINS + 4];
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(256) void sift_orient_kernel(const float *__restric
         if (slot < dv.raw_cap) {
             float *q = raw + ((long long)img * dv.raw_cap + slot) * 6;
             q[0] = kx; q[1] = ky; q[2] = ksize; q[3] = angle; q[4] = kresp; q[5] = __int_as_float(koct);
-        } else overflow[img] = 1;
+        } else atomicOr(&overflow[img], (unsigned)RPE_OVF_SIFT_RAW);
     }
     __builtin_amdgcn_wave_barrier();
     }
@@ -644,7 +648,7 @@ __device__ __forceinline__ unsigned s_float_key(float f)
 // (exact duplicates are rare); otherwise the overflow flag is raised.
 __global__ __launch_bounds__(256) void sift_prefilter_kernel(const float *__restrict__ raw, const int *__restrict__ nraw, SiftDev dv, int pad,
                                                               unsigned long long *__restrict__ k0, unsigned long long *__restrict__ k1,
-                                                              unsigned *__restrict__ sidx, int *__restrict__ ncand, int *__restrict__ overflow)
+                                                              unsigned *__restrict__ sidx, int *__restrict__ ncand, unsigned *__restrict__ overflow)
 {
     __shared__ unsigned s_hist[256];
     __shared__ unsigned s_prefix;
@@ -694,7 +698,7 @@ __global__ __launch_bounds__(256) void sift_prefilter_kernel(const float *__rest
         }
     }
     __syncthreads();
-    if (tid == 0) { ncand[img] = min(s_cnt, pad); if (s_cnt > pad) overflow[img] = 1; }
+    if (tid == 0) { ncand[img] = min(s_cnt, pad); if (s_cnt > pad) atomicOr(&overflow[img], (unsigned)RPE_OVF_SIFT_PREFILTER); }
 }
 
 __global__ __launch_bounds__(1024) void sift_sort_kernel(const int *__restrict__ ncand, int pad,
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(1024) void sift_sort_kernel(const int *__restrict__
 __global__ __launch_bounds__(256) void sift_finalize_kernel(const float *__restrict__ raw, const int *__restrict__ ncand, SiftDev dv, int pad,
                                                              const unsigned long long *__restrict__ k0, const unsigned long long *__restrict__ k1,
                                                              const unsigned *__restrict__ sidx, float *__restrict__ fin,
-                                                             float2 *__restrict__ kp_pt, int *__restrict__ kp_count)
+                                                             float2 *__restrict__ kp_pt, int *__restrict__ kp_count, unsigned *__restrict__ overflow)
 {
     __shared__ unsigned s_hist[256];
     __shared__ int s_wave[5];
@@ -791,7 +795,13 @@ __global__ __launch_bounds__(256) void sift_finalize_kernel(const float *__restr
         }
         offset += total;
     }
-    if (tid == 0) kp_count[img] = min(offset, dv.kcap);
+    if (tid == 0) {
+        kp_count[img] = min(offset, dv.kcap);
+        // the cap removed keypoints: the reference's SIFT_create() is uncapped (pose_estimator.py:93-94), so its
+        // feature set is larger than this one
+        if (dv.nfeatures > 0 && nuniq > dv.nfeatures) atomicOr(&overflow[img], (unsigned)RPE_OVF_SIFT_CAP);
+        if (offset > dv.kcap) atomicOr(&overflow[img], (unsigned)RPE_OVF_SIFT_KEYPOINTS);
+    }
 }
 
 // ---------------------------------------------------------------- descriptor
@@ -1106,27 +1116,27 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
     if (S->n_xtiles)
         hipLaunchKernelGGL(sift_extrema_mask_kernel, dim3((S->n_xtiles + 7) / 8 * 8, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
                            (const SiftXTile *)S->d_xtiles, S->d_xmask, S->d_band_cnt, S->n_xtiles);
-    hipLaunchKernelGGL(sift_band_scan_kernel, dim3(n), dim3(256), 0, h->stream, (const int *)S->d_band_cnt, S->d_band_off, S->d_nseeds, dv);
+    hipMemsetAsync(h->d_ovf, 0, sizeof(unsigned) * n, h->stream);
+    hipLaunchKernelGGL(sift_band_scan_kernel, dim3(n), dim3(256), 0, h->stream, (const int *)S->d_band_cnt, S->d_band_off, S->d_nseeds, h->d_ovf, dv);
     hipLaunchKernelGGL(sift_extrema_emit_kernel, dim3((dv.nbands + 3) / 4, n), dim3(256), 0, h->stream, (const unsigned long long *)S->d_xmask, dv,
                        (const int *)S->d_band_cnt, (const int *)S->d_band_off, S->d_seeds);
     // 4. refine + orientation -> raw keypoints
     hipMemsetAsync(S->d_nraw, 0, sizeof(int) * n, h->stream);
-    hipMemsetAsync(S->d_overflow, 0, sizeof(int) * n, h->stream);
     MARK(h, RPE_STAGE_NMS); MARK(h, RPE_STAGE_SELECT);
     hipMemsetAsync(S->d_nsurv, 0, sizeof(int) * n, h->stream);
     hipLaunchKernelGGL(sift_adjust_kernel, dim3((dv.seed_cap + 255) / 256, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
                        (const unsigned *)S->d_seeds, (const int *)S->d_nseeds, S->d_surv, S->d_nsurv);
     MARK(h, RPE_STAGE_HARRIS);
     hipLaunchKernelGGL(sift_orient_kernel, dim3(2048, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
-                       (const float *)S->d_surv, (const int *)S->d_nsurv, S->d_raw, S->d_nraw, S->d_overflow);
+                       (const float *)S->d_surv, (const int *)S->d_nsurv, S->d_raw, S->d_nraw, h->d_ovf);
     // 5. sort, dedup, retainBest, compaction
     MARK(h, RPE_STAGE_KEYPOINTS);
     hipLaunchKernelGGL(sift_prefilter_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_raw, (const int *)S->d_nraw, dv, S->raw_pad,
-                       S->d_k0, S->d_k1, S->d_sidx, S->d_ncand, S->d_overflow);
+                       S->d_k0, S->d_k1, S->d_sidx, S->d_ncand, h->d_ovf);
     hipLaunchKernelGGL(sift_sort_kernel, dim3(n), dim3(1024), 0, h->stream, (const int *)S->d_ncand, S->raw_pad, S->d_k0, S->d_k1, S->d_sidx);
     hipLaunchKernelGGL(sift_finalize_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_raw, (const int *)S->d_ncand, dv, S->raw_pad,
                        (const unsigned long long *)S->d_k0, (const unsigned long long *)S->d_k1, (const unsigned *)S->d_sidx,
-                       S->d_fin, h->d_kp_pt, h->d_kp_count);
+                       S->d_fin, h->d_kp_pt, h->d_kp_count, h->d_ovf);
     // 6. descriptors
     MARK(h, RPE_STAGE_ANGLE); MARK(h, RPE_STAGE_BLUR); MARK(h, RPE_STAGE_DESCRIBE);
     hipLaunchKernelGGL(sift_describe_kernel, dim3((dv.kcap + 3) / 4, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,

@@ -6,7 +6,10 @@ estimate_with_debug(...) -> dict with the reference's keys (:571-688, dict
 :624-633), same exception types and messages (:96, :129, :508-509, :514-515,
 :529-530).  Added: estimate_batch() for many pairs per call.
 
-Scope: the feature -> match -> essential -> pose path (ORB + Hamming, SIFT + L2) on the GPU.  VP refinement
+Scope: the feature -> match -> essential -> pose path on the GPU: ORB or SIFT features, Hamming or L2 matcher
+(every combination cv2 can run: ORB + Hamming, ORB + L2, SIFT + L2; SIFT + Hamming fails in cv2's match() and is
+rejected here at construction).  Added, opt-in and NOT in the reference: `ratio` = Lowe ratio test instead of
+crossCheck.  VP refinement
 (:160-481, :536-567) is the reference's CPU post-step on R; it is applied exactly where the
 reference applies it -- `use_vp_refinement` set and `R_prev` given -- by vp_refinement.py on top of the
 library's LSD restatement (host code, as in the reference).
@@ -32,7 +35,8 @@ class PoseEstimator:
                  vp_lm_lambda=1e-2,
                  vp_cost_improve_eps=1e-3,
                  device=0,
-                 max_batch=1):
+                 max_batch=1,
+                 ratio=None):
         self.K = np.asarray(camera_matrix, dtype=np.float64)
         self.feature_method = feature_method
         self.norm_type = norm_type
@@ -48,6 +52,7 @@ class PoseEstimator:
         self.vp_cost_improve_eps = vp_cost_improve_eps
         self.device = device
         self.max_batch = max_batch
+        self.ratio = ratio            # None = the reference's crossCheck matcher; a float = knnMatch(k=2) + Lowe ratio (extension)
         # same validation order and messages as _create_feature_extractor / _create_matcher
         method = self.feature_method.upper()
         if method == "ORB":
@@ -63,9 +68,10 @@ class PoseEstimator:
             self._norm = _capi.NORM_L2
         else:
             raise ValueError(f"Unknown norm type: {norm}")
-        if (self._feature, self._norm) not in ((_capi.FEATURE_ORB, _capi.NORM_HAMMING), (_capi.FEATURE_SIFT, _capi.NORM_L2)):
-            # cv2 itself rejects Hamming on float descriptors; ORB + L2 is legal in cv2 but not built here
-            raise NotImplementedError("the MI355X path implements ORB + Hamming and SIFT + L2")
+        if (self._feature, self._norm) == (_capi.FEATURE_SIFT, _capi.NORM_HAMMING):
+            # cv2 builds this matcher (pose_estimator.py:131) but its match() raises on float descriptors
+            # (batchDistance: NORM_HAMMING needs CV_8U); a GPU handle is not created for a path that cannot run
+            raise ValueError("NORM_HAMMING cannot match SIFT's float descriptors (cv2 raises in BFMatcher.match)")
         self._engines = {}
 
     def _engine(self, height, width, batch):
@@ -74,12 +80,17 @@ class PoseEstimator:
         if eng is None or eng.max_batch < batch:
             if eng is not None:
                 eng.close()
-            mm = self.max_matches if self.max_matches is not None else self.nfeatures + 64
             # SIFT: the reference's SIFT_create() is uncapped (nfeatures is documented "ORB only",
-            # pose_estimator.py:41); the GPU workspace needs a bound, so nfeatures caps SIFT too (<= 4032)
+            # pose_estimator.py:41); the GPU workspace needs a bound, so nfeatures caps SIFT too (<= 4032).
+            # When the cap actually removes keypoints the pair carries OVF_SIFT_CAP (last_overflow).
             nf = min(self.nfeatures, 4032) if self._feature == _capi.FEATURE_SIFT else self.nfeatures
+            # max_matches=None is the reference's "no truncation" (pose_estimator.py:150-151): every cross-checked
+            # match is kept, at most one per keypoint = the keypoint capacity nfeatures + 64
+            mm = min(self.max_matches, nf + 64) if self.max_matches is not None else nf + 64
             eng = _capi.Engine(width, height, max_batch=max(batch, self.max_batch), nfeatures=nf,
-                               max_matches=mm, device=self.device, feature_method=self._feature, norm_type=self._norm)
+                               max_matches=mm, device=self.device, feature_method=self._feature, norm_type=self._norm,
+                               match_mode=_capi.MATCH_RATIO if self.ratio is not None else _capi.MATCH_CROSSCHECK,
+                               match_ratio=float(self.ratio) if self.ratio is not None else 0.75)
             self._engines[key] = eng
         return eng
 
@@ -91,6 +102,11 @@ class PoseEstimator:
             raise RuntimeError(f"Insufficient matches: {n_matches} (minimum 5 required)")
         if status == _capi.PAIR_NO_ESSENTIAL:
             raise RuntimeError("Could not estimate Essential matrix.")
+        if status == _capi.PAIR_AMBIGUOUS_ESSENTIAL:
+            # exactly 5 matches, several five-point models: cv2.findEssentialMat returns them stacked (3n x 3) and the
+            # reference's cv2.recoverPose(E, ...) call (pose_estimator.py:533) raises cv2.error with this assertion
+            raise RuntimeError("OpenCV: (-215:Assertion failed) E.cols == 3 && E.rows == 3 in function 'decomposeEssentialMat' "
+                               "(findEssentialMat returned several stacked models for exactly 5 matches)")
 
     @staticmethod
     def _gray(img):
@@ -106,7 +122,13 @@ class PoseEstimator:
         eng = self._engine(H, W, B)
         R, t, inl, nm, st = eng.estimate_batch(imgs1, imgs2, self.K)
         self._last_n_matches = nm
+        self._last_engine, self._last_pairs = eng, B
         return R, t, inl, st
+
+    def last_overflow(self):
+        """OVF_* capacity flags (see _capi) of the pairs of the last estimate_batch / estimate_sequence call: nonzero
+        where a fixed-size GPU workspace truncated a list cv2 would have kept whole (status stays OK)."""
+        return self._last_engine.fetch_overflow(self._last_pairs)
 
     def estimate_sequence(self, frames):
         """Relative poses of consecutive frames (frame i -> i+1): the pair loop of the reference's
@@ -117,6 +139,7 @@ class PoseEstimator:
         eng = self._engine(H, W, F - 1)
         R, t, inl, nm, st = eng.estimate_stream(frames, self.K)
         self._last_n_matches = nm
+        self._last_engine, self._last_pairs = eng, F - 1
         return R, t, inl, st
 
     def _vp_refine(self, R_rel, R_prev, img1, img2):
