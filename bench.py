@@ -7,10 +7,16 @@ batch of synthetic pairs whose images are already resident in HBM; the step ends
 the pose records are in host memory.  Workload (config.workload) = BASELINE configs[1]:
 1024 VGA pairs per GPU, ORB(1000 kp) + BF-Hamming crossCheck + 5-pt RANSAC + recoverPose.
 Weak scaling: every rank processes its own 1024-pair shard; the only collective is the
-RCCL all-gather of 128-byte pose records at the end of each step.
+RCCL all-gather of 128-byte pose records at the end of each step (rpe_gather_poses in
+librpe_amd.so: no torch on the path; the launcher's RANK / WORLD_SIZE / MASTER_PORT
+environment is all that is used).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+The default single-GPU run appends `extra`: BASELINE configs[2]'s shape (128 HD pairs,
+SIFT(2048) + BF-L2) and the consecutive-frame stream (configs[4] stand-in), each with its
+own roofline and cpu_baseline (--no-extra skips them).
 """
 import argparse
 import json
@@ -24,14 +30,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 measured
+# vector-instruction issue peak (MI355X_MICROARCH.md 'Wave scheduling' / cycle constants: a wave64 VALU
+# instruction takes 2 cycles on the 32-wide SIMD with >= 2 waves resident): 256 CUs x 4 SIMDs x 2.4 GHz / 2
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2
+COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")
 
 
 def orb_levels(W, H, nlevels=12, scale=1.1):
-    """ORB pyramid level sizes (orb.cpp: cvRound(size / scale^l)); sum(w*h) must equal rpe_orb_pyramid_pixels()."""
+    """ORB pyramid level sizes (orb.cpp: cvRound(cols * (1.0f / scale_l)), scale_l = (float)pow(1.1f, l));
+    sum(w*h) must equal rpe_orb_pyramid_pixels()."""
     out = []
+    sf = np.float64(np.float32(scale))
     for l in range(nlevels):
-        s = scale ** l
-        out.append((int(np.rint(W / s)), int(np.rint(H / s))))
+        inv = np.float32(1.0) / np.float32(sf ** l)
+        out.append((int(np.rint(np.float32(W) * inv)), int(np.rint(np.float32(H) * inv))))
     return out
 
 
@@ -69,12 +81,14 @@ def stage_bytes(stage, W, H, pyr_px, nkp, mm, method="ORB"):
     lv = orb_levels(W, H)
     assert sum(w * h for w, h in lv) == pyr_px, "level-size formula disagrees with the library"
     live = [(w, h) for w, h in lv if w > 62 and h > 62]
+    nms_survivors = 5 * nkp                      # ~0.3 % of the pyramid pixels survive NMS (measured on the synthetic batch)
     per_image = {
         "pyramid": img + pyr_px,                 # read level 0, write the 12-level pyramid
-        # FAST+NMS run on the border-filtered region only: ring reads reach 4 px past the NMS output [31, w-31)
-        "fast": sum((w - 54) * (h - 54) + (w - 62) * (h - 62) for w, h in live) + 12 * 256 * 4,
+        # FAST+NMS reads the border-filtered region once (ring reads reach 4 px past the NMS output [31, w-31)) and
+        # writes one 4-byte list entry per surviving keypoint + the histograms
+        "fast": sum((w - 54) * (h - 54) for w, h in live) + 4 * nms_survivors + 12 * 256 * 4,
         "nms": 0,                                # fused into fast
-        "select": sum(w * (h - 62) for w, h in live),   # linear scan of the NMS map rows that can hold keypoints
+        "select": 4 * nms_survivors + 12 * 256 * 4 + 4 * 2 * nkp,   # tile lists in, histogram in, ~2*quota candidates out
         "harris": 81 * 2 * nkp + 8 * 2 * nkp,    # 9x9 patch per candidate (~2*quota kept) + record
         "keypoints": 16 * 2 * nkp,
         "angle": 45 * 45 * nkp + 4 * nkp + 32 * nkp,   # fused orientation + descriptor: one 45x45 patch per keypoint in, angle + 32-B descriptor out
@@ -96,21 +110,29 @@ STAGE_KERNEL = {"pyramid": "pyr_resize_kernel", "fast": "fast_nms_kernel", "angl
                 "select": "select_candidates_kernel", "harris": "harris_kernel", "keypoints": "select_keypoints_kernel",
                 "match": "match_hamming_kernel", "ransac": "ransac_*_kernel (group)", "pose": "recover_pose_kernel"}
 # SIFT reuses the stage slots (csrc/sift_kernels.hip rpe_sift_run)
-SIFT_STAGE_KERNEL = {"pyramid": "sift_upsample + sift_blur_fused<R> x16/octave-set (group)", "fast": "sift_extrema_mask_kernel (+scan, emit)",
-                     "select": "sift_adjust_kernel", "harris": "sift_orient_kernel", "keypoints": "sift_prefilter/sort/finalize (group)",
-                     "describe": "sift_describe_kernel", "match": "match_l2_nearest_kernel (+select)",
+SIFT_STAGE_KERNEL = {"pyramid": "sift_blur_fused_kernel", "fast": "sift_extrema_mask_kernel",
+                     "select": "sift_adjust_kernel", "harris": "sift_orient_kernel", "keypoints": "sift_finalize_kernel",
+                     "describe": "sift_describe_kernel", "match": "match_l2_nearest_kernel",
                      "ransac": "ransac_*_kernel (group)", "pose": "recover_pose_kernel"}
+# instruction kind of rpe_calibrate_valu that a stage's inner loop is made of (the measured issue roof it is priced against)
+STAGE_CALIB_KIND = {"fast": 4, "pyramid": 5, "angle": 3, "match": 0, "ransac": 6, "pose": 6, "harris": 5, "select": 5, "keypoints": 5,
+                    "describe": 5, "nms": 5, "blur": 5}
 
 
-def pmc_traffic(stage, pairs_per_launch, W, H, nfeatures):
-    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes),
-    or None when no profile exists for this kernel / workload."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if stage not in STAGE_KERNEL or not os.path.exists(path) or (W, H, nfeatures, pairs_per_launch) != (640, 480, 1000, 1024):
-        return None
-    k = json.load(open(path))["kernels"].get(STAGE_KERNEL[stage])
-    return k["hbm_bytes_per_launch"] if k else None
+def counters_for(workload_key):
+    """Per-kernel PMC numbers of the committed rocprofv3 passes (profiles/r02_counters.json, written by
+    profiles/make_counters.py from separate --pmc runs: FETCH_SIZE, WRITE_SIZE, SQ_*): HBM bytes per launch
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) and SQ_INSTS_VALU per launch, or {} when no profile exists for
+    this workload."""
+    if not os.path.exists(COUNTERS):
+        return {}
+    return json.load(open(COUNTERS)).get(workload_key, {}).get("kernels", {})
+
+
+def kernel_counter(ctr, kernel, field):
+    """sum over the kernels whose name starts with `kernel` (template instances, kernel groups)"""
+    vals = [v[field] * v.get("launches_per_step", 1) for k, v in ctr.items() if k.startswith(kernel) and field in v]
+    return float(sum(vals)) if vals else None
 
 
 def cpu_baseline(i1, i2, K, nfeatures, max_matches, sample, method="ORB"):
@@ -125,12 +147,17 @@ def cpu_baseline(i1, i2, K, nfeatures, max_matches, sample, method="ORB"):
     t0 = time.perf_counter()
     res = oracle.estimate_pose_batch(i1[:n], i2[:n], K, nfeatures, max_matches, nthreads=threads, method=method)
     dt = time.perf_counter() - t0
+    # single-thread latency of one pair: the first pair alone
+    t1 = time.perf_counter()
+    oracle.estimate_pose_batch(i1[:1], i2[:1], K, nfeatures, max_matches, nthreads=1, method=method)
+    lat = time.perf_counter() - t1
     return res, {"value": n / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+                 "single_thread_pair_latency_ms": lat * 1e3,
                  "sample": f"first {n} pairs of the same synthetic batch ({i1.shape[2]}x{i1.shape[1]}, {method} {nfeatures}), "
                            f"{threads} pthreads over pairs, {dt:.1f} s wall"}
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -142,28 +169,28 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--cpu-sample", type=int, default=1024, help="pairs of the batch the CPU oracle is timed on (about 10 s on a 16-core share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[2] / stream lines appended to the default single-GPU run")
+    ap.add_argument("--no-calibrate", action="store_true", help="skip the live VALU / HBM calibration kernels")
     ap.add_argument("--gen-workers", type=int, default=0)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3],
                     help="BASELINE configs[]: 2 = 1024 VGA pairs ORB(1000)+Hamming (the metric's config, default); "
                          "3 = 1920x1080 pairs SIFT(2048)+L2, processed in sub-batches")
     ap.add_argument("--stream", action="store_true",
-                    help="BASELINE configs[4] stand-in: consecutive-frame stream (batch+1 frames -> batch pairs), features once per frame")
-    ap.add_argument("--sub-batch", type=int, default=0, help="pairs per enqueue (config 3 default 32: 1.1 GB of pyramid per pair)")
+                    help="BASELINE configs[4] stand-in: consecutive-frame stream, features once per frame; with --gpus N ONE "
+                         "sequence of N*batch+1 frames is cut into per-rank frame ranges with a one-frame halo")
+    ap.add_argument("--sub-batch", type=int, default=0, help="pairs per enqueue (config 3 default 128: 0.66 GB of pyramid per pair)")
     ap.add_argument("--streams", type=int, default=1, help="split the batch over S engine handles (S HIP streams) so latency-bound stages overlap")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of the N>1 path)")
+    ap.add_argument("--dist-backend", default="rccl", choices=["rccl", "gloo"],
+                    help="rccl (default) = rpe_gather_poses in librpe_amd.so (ncclAllGather, no torch); "
+                         "gloo = torch.distributed rehearsal of the N>1 path on one GPU / CPU")
     ap.add_argument("--data-cache", default="", help="npz file to load/save the synthetic batch (keeps forks out of profiled runs)")
     ap.add_argument("--unique", type=int, default=0, help="generate only this many distinct pairs and tile them to --batch "
                     "(full-size config 3 runs: rendering 4096 HD pairs takes longer than measuring them)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    from relative_pose_estimation_amd import _capi, synthetic, geometry, sharding
-
+def resolve(args):
+    """fills the per-config defaults; returns the workload descriptor"""
     method = "ORB"
     if args.config == 3:
         method = "SIFT"
@@ -175,48 +202,44 @@ def main():
             args.batch = 128
         if args.cpu_sample == 1024:
             args.cpu_sample = 48
+    sub = args.sub_batch or (128 if method == "SIFT" else args.batch)
+    return method, min(sub, args.batch)
+
+
+def generate(args, method, rank, world, workers):
+    """synthetic data of one workload -- called BEFORE any GPU / process-group initialisation because the
+    generator forks worker processes"""
+    from relative_pose_estimation_amd import synthetic, geometry, sharding
     W, H, B = args.width, args.height, args.batch
-    sub = args.sub_batch or (32 if method == "SIFT" else B)
     K = geometry.default_camera_matrix(W, H)
-    cores = os.cpu_count() or 1
-    workers = args.gen_workers or max(1, min(16, cores // max(1, world)))
-    # global pair index space: rank r owns pairs [r*B, (r+1)*B) (weak scaling)
     if args.stream:
-        frames, Rgt, tgt = synthetic.make_stream(B + 1, K, W, H, seed=5_000_011 + rank, workers=workers)
-        i1, i2 = frames[:-1], frames[1:]
-    cache = f"{args.data_cache}.r{rank}.npz" if args.data_cache and not args.stream else ""
+        # ONE sequence of world*B + 1 frames; this rank renders its frame range (its pairs' first frames + 1 halo frame)
+        F = world * B + 1
+        flo, fhi, plo, phi = sharding.shard_stream_bounds(F, rank, world)
+        frames, Rgt, tgt = synthetic.make_stream(F, K, W, H, seed=5_000_011, workers=workers, frame_range=(flo, fhi))
+        return dict(K=K, frames=frames, i1=frames[:-1], i2=frames[1:], Rgt=Rgt, tgt=tgt, first_pair=plo, distinct=B)
+    cache = f"{args.data_cache}.r{rank}.npz" if args.data_cache else ""
     if cache and os.path.exists(cache):
         z = np.load(cache)
         i1, i2, Rgt, tgt = z["i1"], z["i2"], z["R"], z["t"]
         assert i1.shape == (B, H, W), "data cache does not match the requested workload"
-    elif not args.stream:
-        U = min(args.unique, B) if args.unique > 0 else B
-        i1, i2, Rgt, tgt = synthetic.make_batch(U, K, W, H, cfg=2, first=rank * B, workers=workers)
-        if U < B:
-            reps = -(-B // U)
-            i1, i2 = np.concatenate([i1] * reps)[:B], np.concatenate([i2] * reps)[:B]
-            Rgt, tgt = np.concatenate([Rgt] * reps)[:B], np.concatenate([tgt] * reps)[:B]
-        if cache:
-            np.savez(cache, i1=i1, i2=i2, R=Rgt, t=tgt)
+        return dict(K=K, i1=i1, i2=i2, Rgt=Rgt, tgt=tgt, first_pair=rank * B, distinct=(min(args.unique, B) if args.unique > 0 else B))
+    U = min(args.unique, B) if args.unique > 0 else B
+    i1, i2, Rgt, tgt = synthetic.make_batch(U, K, W, H, cfg=2, first=rank * B, workers=workers)
+    if U < B:
+        reps = -(-B // U)
+        i1, i2 = np.concatenate([i1] * reps)[:B], np.concatenate([i2] * reps)[:B]
+        Rgt, tgt = np.concatenate([Rgt] * reps)[:B], np.concatenate([tgt] * reps)[:B]
+    if cache:
+        np.savez(cache, i1=i1, i2=i2, R=Rgt, t=tgt)
+    return dict(K=K, i1=i1, i2=i2, Rgt=Rgt, tgt=tgt, first_pair=rank * B, distinct=U)
 
-    # the process group (and with it the HIP runtime) comes up only AFTER the synthetic batch exists:
-    # the generator forks worker processes, which must not inherit an initialised GPU context
-    dist = None
-    torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if args.dist_backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.dist_backend)
 
-    ndev = _capi.load().rpe_device_count()
-    device = local_rank % max(ndev, 1)
-    gather_dev = None
-    if dist is not None and args.dist_backend == "nccl":
-        gather_dev = torch.device("cuda", local_rank)
+def run_workload(args, method, sub, data, rank, world, device, comm_kind):
+    """times args.steps steps of one workload on this rank's GPU; returns the JSON object (rank 0) or None"""
+    from relative_pose_estimation_amd import _capi, geometry, sharding
+    W, H, B = args.width, args.height, args.batch
+    K, i1, i2, Rgt, tgt = data["K"], data["i1"], data["i2"], data["Rgt"], data["tgt"]
     S = max(1, args.streams)
     bounds = [sharding.shard_bounds(B, s, S) for s in range(S)]
     fm, nt = (_capi.FEATURE_SIFT, _capi.NORM_L2) if method == "SIFT" else (_capi.FEATURE_ORB, _capi.NORM_HAMMING)
@@ -224,9 +247,19 @@ def main():
                          feature_method=fm, norm_type=nt)
             for lo, hi in bounds]
     eng = engs[0]
+    comm = None
+    dist = None
+    if world > 1:
+        assert S == 1 and sub >= B, "multi-GPU runs use one handle and one launch group per rank"
+        if comm_kind == "rccl":
+            comm = sharding.PoseComm(eng, rank, world, tag=f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{args.config}{int(args.stream)}")
+        else:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                dist.init_process_group("gloo")
     if args.stream:
         assert S == 1 and sub >= B, "--stream uses one handle and one launch group"
-        d_frames = engs[0].upload(frames)
+        d_frames = eng.upload(data["frames"])
         dbuf = [(d_frames, d_frames)]
     else:
         dbuf = [(e.upload(i1[lo:hi]), e.upload(i2[lo:hi])) for e, (lo, hi) in zip(engs, bounds)]   # inputs resident in HBM
@@ -236,21 +269,21 @@ def main():
     def barrier():
         for e in engs:
             e.synchronize()
-        if dist is not None:
+        if comm is not None:
+            comm.barrier()
+        elif dist is not None:
             dist.barrier()
-            if gather_dev is not None:
-                torch.cuda.synchronize()
 
     sub_acc = {}
 
     def step():
         if args.stream:
-            engs[0].enqueue_stream_device(dbuf[0][0], B + 1, K)
-            parts = [engs[0].fetch_results(B)]
+            eng.enqueue_stream_device(dbuf[0][0], B + 1, K)
+            parts = None if comm is not None else [eng.fetch_results(B)]
         elif sub >= B:
             for e, (a, b), (lo, hi) in zip(engs, dbuf, bounds):
                 e.enqueue_batch_device(a, b, hi - lo, K)
-            parts = [e.fetch_results(hi - lo) for e, (lo, hi) in zip(engs, bounds)]
+            parts = None if comm is not None else [e.fetch_results(hi - lo) for e, (lo, hi) in zip(engs, bounds)]
         else:                       # sub-batched (workspace-bound configs): one engine, consecutive slices
             import ctypes
             parts = []
@@ -262,10 +295,15 @@ def main():
                 parts.append(e.fetch_results(n))
                 for k, v in e.stage_ms().items():
                     sub_acc[k] = sub_acc.get(k, 0.0) + v
+        if comm is not None:
+            # the pose records of every rank, packed on the device and all-gathered over RCCL / xGMI
+            rec = comm.gather(B, B, data["first_pair"])
+            mine = rec[(rec["pair"] >= data["first_pair"]) & (rec["pair"] < data["first_pair"] + B)]
+            return rec, (mine["R"].reshape(-1, 3, 3), mine["t"].reshape(-1, 3, 1), mine["inliers"], mine["n_matches"], mine["status"])
         R, t, inl, nm, st = (np.concatenate([p[k] for p in parts]) for k in range(5))
-        rec = sharding.pack_records(R, t, inl, st, nm, first_pair=rank * B)
+        rec = sharding.pack_records(R, t, inl, st, nm, first_pair=data["first_pair"])
         if dist is not None:
-            rec = sharding.gather_pose_records(rec, B, device=gather_dev)
+            rec = sharding.gather_pose_records(rec, B)
         return rec, (R, t, inl, nm, st)
 
     for _ in range(args.warmup):
@@ -281,33 +319,77 @@ def main():
                     stage_acc[k] = stage_acc.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev if gather_dev is not None else "cpu")
+    if comm is not None:
+        elapsed = comm.max(elapsed)
+    elif dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    assert len(rec) == world * B and sorted(rec["pair"].tolist()) == list(range(world * B)), "pose gather incomplete"
 
     R, t, inl, nm, st = local
     ok = st == 0
     errs = np.array([geometry.rotation_error(R[i], Rgt[i]) for i in range(B) if ok[i]])
     # translation is recovered up to scale: direction error against the ground-truth direction (pose_evaluator.py:111-116)
     terrs = np.array([geometry.translation_direction_error(t[i], tgt[i]) for i in range(B) if ok[i] and np.linalg.norm(tgt[i]) > 0])
-    # per-LAUNCH averages: every step launches each kernel group once per stream on B/S pairs
+    # per-LAUNCH averages: every step launches each kernel group once per stream on B/S pairs; fused-away slots are dropped
     stage_ms = {k: v / (args.steps * S) for k, v in stage_acc.items()}
     Bl = B // S if B % S == 0 else B / S          # pairs per launch
     if sub < B:
         Bl = sub
         launches = (args.steps + args.warmup) * (-(-B // sub))
         stage_ms = {k: v / launches for k, v in sub_acc.items()}
+    fused = ("nms", "blur", "describe") if method == "ORB" else ("nms", "angle", "blur")
+    stage_ms = {k: v for k, v in stage_ms.items() if k not in fused}
     pyr_px = eng.lib.rpe_orb_pyramid_pixels(eng.h)
 
+    out = None
     if rank == 0:
-        dom = max(stage_ms, key=stage_ms.get)
         names = SIFT_STAGE_KERNEL if method == "SIFT" else STAGE_KERNEL
-        dom_bytes = stage_bytes(dom, W, H, pyr_px, args.nfeatures, args.max_matches, method) * Bl
-        achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
-        # the matcher is the stage north_star attaches a roofline target to: always report it too
-        m_bytes = stage_bytes("match", W, H, pyr_px, args.nfeatures, args.max_matches, method) * Bl
-        m_achieved = m_bytes / (stage_ms["match"] * 1e-3) / 1e9
+        wkey = f"{method}_{W}x{H}_{args.nfeatures}_{int(Bl)}" + ("_stream" if args.stream else "")
+        ctr = counters_for(wkey)
+        calib = {}
+
+        def issue_rate(kind):
+            if args.no_calibrate:
+                return None
+            if kind not in calib:
+                calib[kind] = eng.calibrate_valu(kind, 8)
+            return calib[kind]
+
+        def roof(stage):
+            """both roofs of one stage's kernel: HBM (algorithmic bytes / spec peak) and VALU issue (SQ_INSTS_VALU of the
+            committed PMC pass / measured issue rate of the instruction kind its inner loop is made of)"""
+            ms = stage_ms[stage]
+            b = stage_bytes(stage, W, H, pyr_px, args.nfeatures, args.max_matches, method) * Bl
+            ach = b / (ms * 1e-3) / 1e9
+            r = {"kernel": names.get(stage, stage), "stage": stage, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": ach / HBM_PEAK_GBS, "traffic": kernel_counter(ctr, names.get(stage, stage).split(" ")[0].replace("_*_kernel", "_"), "hbm_bytes_per_launch"),
+                 "algorithmic_bytes_per_launch": b, "avg_launch_ms": ms}
+            insts = kernel_counter(ctr, names.get(stage, stage).split(" ")[0].replace("_*_kernel", "_"), "valu_insts_per_launch")
+            rate = issue_rate(STAGE_CALIB_KIND.get(stage, 5))
+            if insts is not None:
+                v = {"insts": insts, "insts_per_s": insts / (ms * 1e-3), "spec_peak_insts_per_s": VALU_PEAK_WAVE_INSTS,
+                     "frac_of_spec": insts / (ms * 1e-3) / VALU_PEAK_WAVE_INSTS}
+                if rate is not None:
+                    v.update({"measured_peak_insts_per_s": rate[1], "calibration_instruction": rate[0], "frac": insts / (ms * 1e-3) / rate[1]})
+                else:
+                    v["frac"] = v["frac_of_spec"]
+                r["valu"] = v
+                r["bound"] = "valu" if v["frac"] > r["frac"] else "hbm"
+            else:
+                r["bound"] = "hbm"
+            return r
+
+        dom = max(stage_ms, key=stage_ms.get)
+        rl = roof(dom)
+        rl["matcher"] = roof("match")              # the stage north_star attaches a roofline target to: always reported
+        if not args.no_calibrate:
+            try:
+                rl["hbm_measured_gbs"] = eng.calibrate_hbm() / 1e9
+            except _capi.RpeError:
+                rl["hbm_measured_gbs"] = None
         out = {
             "metric": "image-pairs/s end-to-end (640x480 pairs), median rotation-angle error alongside",
             "value": world * B * args.steps / elapsed,
@@ -323,19 +405,18 @@ def main():
             "data": "synthetic",
             "config": {"workload": (f"{B} {W}x{H} pairs per GPU, ORB({args.nfeatures}kp)+BF-Hamming crossCheck top-{args.max_matches}"
                                     "+5pt-RANSAC(0.999,1px)+recoverPose (BASELINE configs[1])" +
-                                    (f"; consecutive-frame stream of {B + 1} frames, features once per frame (configs[4] stand-in)" if args.stream else "")) if method == "ORB" else
+                                    (f"; ONE consecutive-frame stream of {world * B + 1} frames cut into {world} frame ranges with a one-frame halo, "
+                                     "features once per frame (configs[4] stand-in)" if args.stream else "")) if method == "ORB" else
                                    (f"{B} {W}x{H} pairs per GPU in sub-batches of {sub}, SIFT(cap {args.nfeatures})+BF-L2 crossCheck "
                                     f"top-{args.max_matches}+5pt-RANSAC+recoverPose (BASELINE configs[2]" + ("" if B >= 4096 else f" shape, {B} of its 4096 pairs") + ")"),
-                       "pairs_per_gpu": B, "distinct_pairs": (min(args.unique, B) if args.unique > 0 else B), "global_pairs": world * B, "streams_per_gpu": S, "pairs_per_launch": Bl, "sharding": f"pairs x{world}, RCCL all-gather of 128-B pose records"},
+                       "pairs_per_gpu": B, "distinct_pairs": data["distinct"], "global_pairs": world * B, "streams_per_gpu": S, "pairs_per_launch": Bl,
+                       "sharding": f"pairs x{world}, " + ("rpe_gather_poses: ncclAllGather (RCCL) of 128-B pose records, no torch" if comm_kind == "rccl" or world == 1
+                                                         else "torch.distributed gloo all-gather of 128-B pose records (rehearsal)")},
             "median_rotation_error_deg": float(np.median(errs)) if len(errs) else None,
             "median_translation_dir_error_deg": float(np.median(terrs)) if len(terrs) else None,
             "pairs_ok": int(ok.sum()),
             "stage_ms_per_launch": {k: round(v, 4) for k, v in stage_ms.items()},
-            "roofline": {"kernel": names.get(dom, dom), "stage": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, Bl, W, H, args.nfeatures),
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": stage_ms[dom],
-                         "matcher": {"achieved": m_achieved, "frac": m_achieved / HBM_PEAK_GBS,
-                                     "algorithmic_bytes_per_launch": m_bytes, "avg_launch_ms": stage_ms["match"]}},
+            "roofline": rl,
         }
         if not args.no_cpu_baseline and world == 1:
             res, cb = cpu_baseline(i1, i2, K, args.nfeatures, args.max_matches, args.cpu_sample, method)
@@ -348,13 +429,52 @@ def main():
                        np.linalg.norm(res["R"][i].reshape(3, 3) - R[i]) <= 1e-4 for i in range(n))
             cb["gpu_matches_cpu_on_sample"] = bool(same)
             out["cpu_baseline"] = cb
-        print(json.dumps(out), flush=True)
 
+    if comm is not None:
+        comm.barrier()
+        comm.close()
     for e in engs:
         e.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    method, sub = resolve(args)
+    cores = os.cpu_count() or 1
+    workers = args.gen_workers or max(1, min(16, cores // max(1, world)))
+
+    # ---- all synthetic data first (the generator forks): headline + the two extra workloads of the default run
+    data = generate(args, method, rank, world, workers)
+    want_extra = (world == 1 and not args.no_extra and args.config == 2 and not args.stream and args.streams == 1 and
+                  args.batch == 1024 and (args.width, args.height, args.nfeatures) == (640, 480, 1000))
+    extras = []
+    if want_extra:
+        a3 = argparse.Namespace(**vars(args))
+        a3.config, a3.steps, a3.warmup, a3.unique, a3.cpu_sample, a3.data_cache = 3, 2, 1, 16, 16, ""
+        m3, s3 = resolve(a3)
+        extras.append(("config3_128pairs", a3, m3, s3, generate(a3, m3, 0, 1, workers)))
+        ast = argparse.Namespace(**vars(args))
+        ast.stream, ast.cpu_sample, ast.data_cache = True, 256, ""
+        extras.append(("stream", ast, "ORB", ast.batch, generate(ast, "ORB", 0, 1, workers)))
+
+    from relative_pose_estimation_amd import _capi
+    ndev = _capi.load().rpe_device_count()
+    device = local_rank % max(ndev, 1)
+    out = run_workload(args, method, sub, data, rank, world, device, args.dist_backend)
+    if rank == 0 and extras:
+        out["extra"] = {}
+        for name, a, m, s, d in extras:
+            o = run_workload(a, m, s, d, 0, 1, device, "rccl")
+            out["extra"][name] = {k: o[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "median_rotation_error_deg", "pairs_ok",
+                                                    "stage_ms_per_launch", "roofline", "cpu_baseline") if k in o}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -88,7 +88,7 @@ typedef struct rpe_config {
     int32_t max_batch;        /* max pairs per call */
     int32_t feature_method;   /* RPE_FEATURE_ORB        (pose_estimator.py:22) */
     int32_t norm_type;        /* RPE_NORM_HAMMING       (pose_estimator.py:23) */
-    int32_t max_matches;      /* default 500            (pose_estimator.py:24); 5 .. nfeatures+64 (= keypoint capacity: "no truncation", :150-151) */
+    int32_t max_matches;      /* default 500            (pose_estimator.py:24); 5 .. 8064; >= nfeatures+64 (the keypoint capacity) = "no truncation" (:150-151) */
     int32_t nfeatures;        /* default 4000           (pose_estimator.py:25) */
     int32_t fast_threshold;   /* 15                     (pose_estimator.py:89) */
     int32_t ransac_max_iters; /* 1000 (cv2 default maxIters) */
@@ -249,6 +249,29 @@ enum {
 int rpe_set_profiling(rpe_handle *h, int enable);
 int rpe_get_stage_ms(rpe_handle *h, float *ms /* RPE_STAGE_COUNT */);
 const char *rpe_stage_name(int stage);
+
+/* ------------------------------------------------------------- multi-GPU */
+/* The path shards by independent pairs (the reference never chains estimates, batch_processor.py:82-92): one process
+ * and one handle per GPU, no data-path exchange.  The single collective is the final pose gather: every rank contributes
+ * per_rank 128-byte records and receives all of them -- ncclAllGather over RCCL / xGMI on the handle's stream.  librccl is
+ * loaded lazily by the first rpe_comm_* call.  Bootstrap: rank 0 calls rpe_comm_unique_id and hands the 128 bytes to the
+ * other ranks by any means (sharding.py uses a file next to the launcher's MASTER_PORT); every rank then calls
+ * rpe_comm_create.  Record layout (RPE_POSE_RECORD_BYTES = 128): double R[9]; double t[3]; int32 inliers, status,
+ * n_matches, pair (global pair index, -1 for padding); 16 bytes reserved. */
+#define RPE_COMM_ID_BYTES 128
+#define RPE_POSE_RECORD_BYTES 128
+typedef struct rpe_comm rpe_comm;
+int rpe_comm_unique_id(uint8_t id[RPE_COMM_ID_BYTES]);
+int rpe_comm_create(rpe_handle *h, int rank, int world, const uint8_t id[RPE_COMM_ID_BYTES], rpe_comm **out);
+int rpe_comm_destroy(rpe_comm *c);
+const char *rpe_comm_last_error(void);
+/* packs the results of the handle's last batch (n_local pairs, global indices first_pair ..) into records on the
+ * device, all-gathers per_rank records per rank (n_local <= per_rank <= max_batch; padded with pair = -1) and copies
+ * the world * per_rank records to h_records (host, world * per_rank * 128 bytes), rank-major. */
+int rpe_gather_poses(rpe_handle *h, rpe_comm *c, int n_local, int per_rank, int first_pair, void *h_records);
+/* max over ranks of one host double (step timing); rpe_comm_barrier = the same exchange without a value */
+int rpe_comm_allreduce_max(rpe_comm *c, double *value);
+int rpe_comm_barrier(rpe_comm *c);
 
 /* ---------------------------------------------------- roofline calibration */
 /* Measured vector-instruction ISSUE rate of this device (wave-instructions per second, whole chip) for one

@@ -35,6 +35,8 @@ EXPORTS = [
     "rpe_estimate_stream", "rpe_enqueue_stream_device",
     "rpe_bgr_to_gray_device", "rpe_bgr_to_gray", "rpe_lsd_detect",
     "rpe_fetch_overflow", "rpe_calibrate_valu", "rpe_calibrate_valu_name", "rpe_calibrate_hbm",
+    "rpe_comm_unique_id", "rpe_comm_create", "rpe_comm_destroy", "rpe_comm_last_error", "rpe_gather_poses",
+    "rpe_comm_allreduce_max", "rpe_comm_barrier",
 ]
 
 
@@ -114,6 +116,13 @@ def load():
     lib.rpe_calibrate_valu.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]; lib.rpe_calibrate_valu.restype = C.c_int
     lib.rpe_calibrate_valu_name.argtypes = [C.c_int]; lib.rpe_calibrate_valu_name.restype = C.c_char_p
     lib.rpe_calibrate_hbm.argtypes = [vp, C.POINTER(C.c_double)]; lib.rpe_calibrate_hbm.restype = C.c_int
+    lib.rpe_comm_unique_id.argtypes = [vp]; lib.rpe_comm_unique_id.restype = C.c_int
+    lib.rpe_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]; lib.rpe_comm_create.restype = C.c_int
+    lib.rpe_comm_destroy.argtypes = [vp]; lib.rpe_comm_destroy.restype = C.c_int
+    lib.rpe_comm_last_error.argtypes = []; lib.rpe_comm_last_error.restype = C.c_char_p
+    lib.rpe_gather_poses.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]; lib.rpe_gather_poses.restype = C.c_int
+    lib.rpe_comm_allreduce_max.argtypes = [vp, C.POINTER(C.c_double)]; lib.rpe_comm_allreduce_max.restype = C.c_int
+    lib.rpe_comm_barrier.argtypes = [vp]; lib.rpe_comm_barrier.restype = C.c_int
     _lib = lib
     return lib
 

@@ -310,7 +310,7 @@ extern "C" int rpe_create(const rpe_config *cfg, rpe_handle **out)
         g_create_err = "SIFT: nfeatures (keypoint cap) must be <= 4032 and the image <= 4000 px"; return RPE_ERR_INVALID;
     }
     if (cfg->width < 96 || cfg->height < 96 || cfg->width > 4095 || cfg->height > 4095 || cfg->max_batch < 1 ||
-        cfg->nfeatures < 1 || cfg->nfeatures > 8000 || cfg->max_matches < 5 || cfg->max_matches > cfg->nfeatures + 64 ||
+        cfg->nfeatures < 1 || cfg->nfeatures > 8000 || cfg->max_matches < 5 || cfg->max_matches > 8064 ||
         cfg->ransac_max_iters < 1 || cfg->ransac_max_iters > 4096 || cfg->fast_threshold < 1 || cfg->fast_threshold > 254) {
         g_create_err = "configuration out of supported range"; return RPE_ERR_INVALID;
     }

@@ -113,11 +113,14 @@ def _stream_job(args):
     return _finish(_render(K, R, t, W, H, int(seed), focal), rng)
 
 
-def make_stream(n_frames, K, W=640, H=480, seed=5_000_011, max_angle_deg=2.0, step=0.12, workers=1):
+def make_stream(n_frames, K, W=640, H=480, seed=5_000_011, max_angle_deg=2.0, step=0.12, workers=1, frame_range=None):
     """One camera moving through ONE scene (KITTI-like consecutive-frame stream, BASELINE config 5
     stand-in): frames [n,H,W], and the ground-truth relative pose of every consecutive pair
     (X_{i+1} = R_rel X_i + t_rel, |t_rel| = 1).  The camera random-walks with small rotations and
-    a bounded position so that the scene stays in view."""
+    a bounded position so that the scene stays in view.
+    frame_range=(lo, hi): render only frames [lo, hi) of the n_frames-long sequence (the trajectory is always
+    computed whole, so every shard of a sharded stream sees the same sequence); poses returned are those of the
+    pairs inside the range."""
     rng = np.random.default_rng(int(seed))
     K = np.asarray(K, np.float64)
     focal = 0.5 * (K[0, 0] + K[1, 1])
@@ -130,14 +133,15 @@ def make_stream(n_frames, K, W=640, H=480, seed=5_000_011, max_angle_deg=2.0, st
             d = -Rs[-1] @ (c_prev / np.linalg.norm(c_prev))
         tr = d * step
         Rs.append(Rr @ Rs[-1]); ts.append(Rr @ ts[-1] + tr)
-    jobs = [(K, Rs[i], ts[i], W, H, seed, focal, seed * 31 + i) for i in range(n_frames)]
+    lo, hi = (0, n_frames) if frame_range is None else (int(frame_range[0]), int(frame_range[1]))
+    jobs = [(K, Rs[i], ts[i], W, H, seed, focal, seed * 31 + i) for i in range(lo, hi)]
     if workers > 1:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(workers) as pool:
-            frames = pool.map(_stream_job, jobs, chunksize=max(1, n_frames // (workers * 4)))
+            frames = pool.map(_stream_job, jobs, chunksize=max(1, len(jobs) // (workers * 4)))
     else:
         frames = [_stream_job(j) for j in jobs]
-    R_rel = np.stack([Rs[i + 1] @ Rs[i].T for i in range(n_frames - 1)])
-    t_rel = np.stack([(ts[i + 1] - Rs[i + 1] @ Rs[i].T @ ts[i]) for i in range(n_frames - 1)])
+    R_rel = np.stack([Rs[i + 1] @ Rs[i].T for i in range(lo, hi - 1)])
+    t_rel = np.stack([(ts[i + 1] - Rs[i + 1] @ Rs[i].T @ ts[i]) for i in range(lo, hi - 1)])
     t_rel = t_rel / np.linalg.norm(t_rel, axis=1, keepdims=True)
     return np.stack(frames), R_rel, t_rel.reshape(-1, 3, 1)

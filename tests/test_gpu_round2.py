@@ -280,3 +280,27 @@ def test_full_batch_properties(capi, oracle, K_vga):
         r = oracle.estimate_pose(i1[u], i2[u], K_vga, 1000, 500)
         assert np.array_equal(R[sel[0]], r["R"]) and np.array_equal(t[sel[0]], r["t"]) and inl[sel[0]] == r["inliers"]
     e.close()
+
+
+# ------------------------------------------------------------------ the one collective: rpe_gather_poses over RCCL
+def test_native_pose_gather_world1(capi, K_vga):
+    """rpe_gather_poses (records packed on the device, ncclAllGather on the handle's stream, no torch) with a
+    one-rank communicator on the 1-GPU box: the gathered records are the batch's results, padding is dropped,
+    pair indices carry the shard offset; the scalar max-reduce / barrier round-trips."""
+    from relative_pose_estimation_amd import sharding, synthetic
+    i1, i2, _, _ = synthetic.make_batch(3, K_vga, cfg=2)
+    i1 = np.concatenate([i1, np.full((1, 480, 640), 60, np.uint8)]); i2 = np.concatenate([i2, i2[:1]])   # a failing pair too
+    e = capi.Engine(640, 480, max_batch=8, nfeatures=1000, max_matches=500)
+    da, db = e.upload(i1), e.upload(i2)
+    e.enqueue_batch_device(da, db, 4, K_vga)
+    comm = sharding.PoseComm(e, 0, 1, tag=f"pytest_{__import__('os').getpid()}")
+    rec = comm.gather(4, 8, first_pair=1000)                      # per_rank 8 > n_local 4: four padding records dropped
+    R, t, inl, nm, st = e.fetch_results(4)
+    assert rec.dtype == sharding.RECORD_DTYPE and rec["pair"].tolist() == [1000, 1001, 1002, 1003]
+    assert np.array_equal(rec["R"].reshape(4, 3, 3), R) and np.array_equal(rec["t"].reshape(4, 3, 1), t)
+    assert np.array_equal(rec["inliers"], inl) and np.array_equal(rec["status"], st) and np.array_equal(rec["n_matches"], nm)
+    assert st[3] == capi.PAIR_NO_DESCRIPTORS and (st[:3] == 0).all()
+    assert comm.max(3.25) == 3.25
+    comm.barrier()
+    comm.close()
+    e.close()

@@ -37,6 +37,39 @@ def test_shard_bounds():
     assert shard_bounds(2, 3, 4) == (2, 2)
 
 
+def test_shard_stream_bounds():
+    """configs[4]: one sequence over the ranks with a one-frame halo -- every pair exactly once, every rank's frame
+    range = its pairs' first frames + one shared frame."""
+    from relative_pose_estimation_amd.sharding import shard_stream_bounds
+    for F, world in ((4541, 8), (880, 8), (10, 4), (3, 8), (2, 2), (1, 2)):
+        seen = []
+        for r in range(world):
+            flo, fhi, plo, phi = shard_stream_bounds(F, r, world)
+            if phi > plo:
+                assert (flo, fhi) == (plo, phi + 1)          # frames p .. p_last + 1: one halo frame
+                assert fhi <= F
+            else:
+                assert flo == fhi
+            seen += list(range(plo, phi))
+        assert seen == list(range(max(F - 1, 0)))
+    assert shard_stream_bounds(4541, 0, 8) == (0, 569, 0, 568) and shard_stream_bounds(4541, 7, 8) == (3976, 4541, 3976, 4540)
+
+
+def test_stream_shards_equal_whole_stream(oracle):
+    """the halo split changes nothing: pair p computed inside its shard (frames re-indexed from the shard's first
+    frame) equals pair p of the unsharded sequence (oracle as the per-rank engine on a CPU box)"""
+    from relative_pose_estimation_amd import synthetic, geometry
+    from relative_pose_estimation_amd.sharding import shard_stream_bounds
+    K = geometry.default_camera_matrix(320, 240)
+    frames, _, _ = synthetic.make_stream(6, K, 320, 240, seed=77, workers=1)
+    whole = oracle.estimate_pose_batch(frames[:-1], frames[1:], K, 300, 200, nthreads=2)
+    for r in range(2):
+        flo, fhi, plo, phi = shard_stream_bounds(6, r, 2)
+        sh = frames[flo:fhi]
+        part = oracle.estimate_pose_batch(sh[:-1], sh[1:], K, 300, 200, nthreads=2)
+        assert len(part) == phi - plo and np.array_equal(part["R"], whole["R"][plo:phi]) and np.array_equal(part["inliers"], whole["inliers"][plo:phi])
+
+
 def test_gloo_world2_gather(tmp_path, oracle):
     out = str(tmp_path / "rec.npy")
     env = dict(os.environ, RPE_ROOT=ROOT, RPE_OUT=out, MASTER_ADDR="127.0.0.1")
