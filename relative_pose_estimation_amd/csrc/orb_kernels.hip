@@ -59,15 +59,21 @@ __device__ __forceinline__ int xcd_tile(int b, int n)
 // Workgroup = 128x64 destination tile of level l.  The source footprint in level l-1
 // (<= 74 rows x 152 bytes, bounds derived arithmetically so the loads do not depend on
 // the coefficient tables; checked on the host) is staged in LDS with aligned dword loads, all of
-// them in flight before the first LDS store -- ~11 KB per workgroup: the kernel is bound by the
-// HBM round trip of that window, so a wider tile (half as many workgroups, twice the bytes in
-// flight each) is what shortens it; one lane = 8 rows x 4 destination pixels.
+// them in flight before the first LDS store -- ~13 KB per workgroup.
+// One lane = 4 destination columns x 8 CONSECUTIVE destination rows.  The bilinear chain is separable in exact
+// integer arithmetic: h(src row, dst col) = a0 p[o] + a1 p[o+1] (16 bits), out = (b0 h(top) + b1 h(bottom) + 2^15) >> 16.
+// At scale 1.1 consecutive destination rows share a source row (bottom of one = top of the next in 9 of 10 steps),
+// so a lane keeps the last bottom row's four h values and computes ~1.1 horizontal rows per output row instead of 2.
+// A horizontal row costs three aligned LDS dwords (the 4 columns span <= 6 source bytes), two v_alignbyte to
+// the lane's byte phase and two v_perm_b32 with per-lane selectors that gather p[o_j] and p[o_j + 1] of the
+// four columns -- instead of eight byte reads.  Reading p[o+1] unclamped is exact: the coefficient table gives
+// weight 0 wherever OpenCV clamps (last source column).
 #define PYR_TW 128
 #define PYR_ROWS 74
 #define PYR_DW 44                    // 176 B per window row = 11 x 16-B loads (origin aligned down to 16 B)
 __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDeviceLayout lay, const int *__restrict__ coef, int l)
 {
-    __shared__ __attribute__((aligned(16))) unsigned s_src[PYR_ROWS * PYR_DW];
+    __shared__ __attribute__((aligned(16))) unsigned s_src[PYR_ROWS * PYR_DW + 4];   // +4: the unclamped p[o+1] of the last row's last column
     const RpeLevel &S = lay.lv[l - 1];
     const RpeLevel &D = lay.lv[l];
     const int tid = threadIdx.x;
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
     // conservative footprint: floor(scale*x0) <= xo[x0] (scale >= 1), checked on the host
     const int a0 = ((int)(((long long)x0 * S.w) / D.w)) & ~15;
     const int sy0 = (int)(((long long)y0 * S.h) / D.h);
-    const int tx = tid & 31, tyb = tid >> 5;
+    const int tx = tid & 31, ty8 = tid >> 5;
     const int x4 = x0 + 4 * tx;
     {   // all window loads (16 B per lane) in flight before the first LDS store (one HBM round trip per tile)
         constexpr int NQ = PYR_DW / 4, NLD = (PYR_ROWS * NQ + 255) / 256;
@@ -97,35 +103,58 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
 #pragma unroll
         for (int q = 0; q < NLD; ++q) { const int i = tid + 256 * q; if (i < PYR_ROWS * NQ) ((uint4 *)s_src)[i] = stage[q]; }
     }
+    // per-lane column constants: source offsets o_j (non-decreasing, o_3 - o_0 <= 4), weights, byte selectors
     int o[4], a1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int cv = cxp[min(x4 + j, D.w - 1)]; o[j] = cv & 0xFFFF; a1[j] = cv >> 16; }
+    const int bcol = o[0] - a0;                                 // window byte column of o_0
+    const int dw0 = bcol >> 2, sh = bcol & 3;
+    unsigned sel0 = 0, sel1 = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned rel = (unsigned)min(max(o[j] - o[0], 0), 4);   // columns past D.w repeat the last entry: rel stays in range
+        sel0 |= rel << (8 * j);
+        sel1 |= (rel + 1u) << (8 * j);
+    }
     int oy[8], b1[8];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) { const int cv = cyp[min(y0 + tyb + 8 * rr, D.h - 1)]; oy[rr] = cv & 0xFFFF; b1[rr] = cv >> 16; }
+    for (int rr = 0; rr < 8; ++rr) { const int cv = cyp[min(y0 + ty8 * 8 + rr, D.h - 1)]; oy[rr] = cv & 0xFFFF; b1[rr] = cv >> 16; }
     __syncthreads();
     if (x4 >= D.pitch) return;
-    const uint8_t *sb = (const uint8_t *)s_src;
+    // horizontal pass of one source row for this lane's 4 columns
+    auto hrow = [&](int srow, unsigned (&hh)[4]) {
+        const unsigned *rw = s_src + (srow - sy0) * PYR_DW + dw0;
+        const unsigned d0 = rw[0], d1 = rw[1], d2 = rw[2];
+        const unsigned w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        const unsigned p0 = __builtin_amdgcn_perm(w1, w0, sel0), p1 = __builtin_amdgcn_perm(w1, w0, sel1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)   // all factors fit 24 bits: v_mul_u32_u24 / v_mad_u32_u24 (full rate)
+            hh[j] = __umul24(256u - (unsigned)a1[j], (p0 >> (8 * j)) & 255u) + __umul24((unsigned)a1[j], (p1 >> (8 * j)) & 255u);
+    };
+    unsigned hc[4] = {0, 0, 0, 0};
+    int cached = -1;
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-        const int y = y0 + tyb + 8 * rr;
+        const int y = y0 + ty8 * 8 + rr;
         if (y >= D.h) break;
-        const int b0 = 256 - b1[rr];
-        const uint8_t *r0 = sb + (oy[rr] - sy0) * (PYR_DW * 4) - a0;
-        const uint8_t *r1 = sb + (min(oy[rr] + 1, S.h - 1) - sy0) * (PYR_DW * 4) - a0;
+        const int top = oy[rr], bot = min(top + 1, S.h - 1);
+        unsigned ht[4];
+        if (top == cached) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ht[j] = hc[j];
+        } else hrow(top, ht);
+        if (bot != top) hrow(bot, hc);
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hc[j] = ht[j];
+        }
+        cached = bot;
+        const unsigned b1u = (unsigned)b1[rr], b0u = 256u - b1u;
         unsigned out = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            unsigned v = 0;
-            if (x4 + j < D.w) {
-                // all factors fit 24 bits: v_mad_u32_u24 (full rate) instead of the quarter-rate 32-bit multiply
-                const int o0 = o[j], o1 = min(o0 + 1, S.w - 1);
-                const unsigned a0c = 256u - (unsigned)a1[j], a1u = (unsigned)a1[j];
-                const unsigned h0 = __umul24(a0c, r0[o0]) + __umul24(a1u, r0[o1]);
-                const unsigned h1 = __umul24(a0c, r1[o0]) + __umul24(a1u, r1[o1]);
-                v = (__umul24((unsigned)b0, h0) + __umul24((unsigned)b1[rr], h1) + 32768u) >> 16;
-            }
-            out |= v << (8 * j);
+            const unsigned v = (__umul24(b0u, ht[j]) + __umul24(b1u, hc[j]) + 32768u) >> 16;
+            out |= (x4 + j < D.w ? v : 0u) << (8 * j);
         }
         *(unsigned *)(base + D.off + (long long)y * D.pitch + x4) = out;
     }
