@@ -626,14 +626,28 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const double2 *__rest
     const float thr2 = (float)(thr * thr);
     const SampsonBound sbound = sampson_bound(thr2);
     const int total = s_first[64];
-    int k = 0;
-    for (int j = wv; j < total; j += 4) {            // j-th model of this group, flattened (iteration-major)
-        while (s_first[k + 1] <= j) ++k;
+    // a wave scores models j = wv, wv + 4, ... one after the other; the 72 bytes of the NEXT model are fetched (lanes 0..8,
+    // one double each) before the current one is scored, so the HBM / L2 round trip of the model hides behind ~400
+    // instructions of Sampson arithmetic instead of heading every iteration (the kernel ran at 28 % of its issue roof)
+    int k = 0, kn = 0;
+    double e_next = 0.;
+    int j = wv;
+    if (j < total) {
+        while (s_first[kn + 1] <= j) ++kn;
+        if (lane < 9) e_next = models[((slot0 + kn) * RPE_MAX_MODELS + (j - s_first[kn])) * 9 + lane];
+    }
+    for (; j < total; j += 4) {                      // j-th model of this group, flattened (iteration-major)
+        k = kn;
         const int m = j - s_first[k];
-        const double *Eg = models + ((slot0 + k) * RPE_MAX_MODELS + m) * 9;
+        const double e_cur = e_next;
+        const int jn = j + 4;
+        if (jn < total) {
+            while (s_first[kn + 1] <= jn) ++kn;
+            if (lane < 9) e_next = models[((slot0 + kn) * RPE_MAX_MODELS + (jn - s_first[kn])) * 9 + lane];
+        }
         double E[9];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) E[e] = Eg[e];
+        for (int e = 0; e < 9; ++e) E[e] = __shfl(e_cur, e);
         int cnt = 0;
         for (int i = lane; i < M; i += 64) {
             double2 a = sp1[i], b = sp2[i];
@@ -787,7 +801,9 @@ void rpe_launch_ransac(rpe_handle *h, int B, bool want_mask)
     hipLaunchKernelGGL(ransac_prepare_kernel, dim3((mm + 255) / 256, B), dim3(256), 0, h->stream,
                        h->d_pts1, h->d_pts2, h->d_m_n, h->d_K, n1, n2, h->d_rstate, h->d_found, mm, it);
     // chunk schedule 64, 64, 128, 256, 512, 512, ...: most pairs stop inside the first 64 iterations;
-    // launches are bound by single-wave latency, so long-running pairs get more waves per launch
+    // launches are bound by single-wave latency, so long-running pairs get more waves per launch.
+    // (64, 512, 512 was measured in round 2: 2.05 -> 2.11 ms -- every wave of the poly kernel reserves 100 KB of
+    // LDS, so the 8 x 1024 mostly empty waves of a 512-chunk queue up one per CU.)
     const int use_lds = mm <= 2048;
     const size_t lds = use_lds ? sizeof(double2) * 2 * (size_t)mm : 0;
     int done_iters = 0, chunk = 64, nlaunch = 0;

@@ -20,6 +20,7 @@
 // m.distance < ratio * n.distance); queries with fewer than two candidates emit nothing.  Sort / truncation /
 // point gather are shared.
 #include "rpe_internal.h"
+#include <stdlib.h>
 
 #define QTILE 1024
 
@@ -135,6 +136,158 @@ __global__ __launch_bounds__(256) void match_hamming_kernel(const uint8_t *__res
     if (tid == 0) m_n[pair] = nm;
 }
 
+// ---------------------------------------------------------------- crossCheck on the matrix cores
+// The measured bound of the VALU kernel above is vector-instruction issue: 19 instructions per 64 distances
+// (8 v_xor + 8 v_bcnt + compare / select) at the 4-cycle integer issue cadence = 0.75 ms for 1024 pairs of
+// 1000 x 1000 descriptors, 91 % of the measured issue roof (profiles/r02_counters.json, r02_calibration.json).
+// Hamming distance is a dot product in disguise: d(q, t) = |q| + |t| - 2 q.t with the 256 bits as 0/1 bytes, so the
+// O(N^2) part goes to v_mfma_i32_32x32x32_i8 (exact integers): 8 MFMAs = one 32 x 32 tile of q.t over K = 256.
+// What is left for the vector ALU per tile is the O(N) bit -> byte expansion and a 2-instruction epilogue per
+// accumulator: key = ((|q| + 512) << 16 | queryIdx) - (q.t << 17) (one v_mad_i32_i24), running v_min_u32 per train
+// column -- the minimum of (distance, queryIdx) keys IS batchDistance's "strict <, ascending query" election.
+// Workgroup = one pair, 8 waves; wave w owns train tile 8 p + w of pass p (its 32 descriptors expanded once into
+// 32 VGPRs: the B operand of all 8 K-steps), the query tiles stream through LDS, expanded by all 512 threads
+// (16 bits -> 16 bytes: nibble * 0x00204081 & 0x01010101), double buffered: one barrier per query tile.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+#define MM_NT 512
+
+__device__ __forceinline__ v4i_t expand16(unsigned b)
+{
+    v4i_t r;
+    r.x = (int)(__umul24(b & 15u, 0x00204081u) & 0x01010101u);
+    r.y = (int)(__umul24((b >> 4) & 15u, 0x00204081u) & 0x01010101u);
+    r.z = (int)(__umul24((b >> 8) & 15u, 0x00204081u) & 0x01010101u);
+    r.w = (int)(__umul24((b >> 12) & 15u, 0x00204081u) & 0x01010101u);
+    return r;
+}
+
+__global__ __launch_bounds__(MM_NT) void match_hamming_mfma_kernel(const uint8_t *__restrict__ desc, const int *__restrict__ kp_count,
+                                                                    const float2 *__restrict__ kp_pt, int img2_base, int kcap,
+                                                                    int max_matches,
+                                                                    int *__restrict__ m_q, int *__restrict__ m_t, int *__restrict__ m_d,
+                                                                    int *__restrict__ m_n, float2 *__restrict__ pts1, float2 *__restrict__ pts2)
+{
+    extern __shared__ uint4 s_dyn[];
+    // [0, 32 KB): two expanded query tiles (2 x 8 K-steps x 64 lanes x 16 B = 16 KB) + their packed (|q| + 512, index)
+    // words; reused as the sort-key array afterwards.  Then kcap election words.
+    v4i_t *s_a = (v4i_t *)s_dyn;                               // [2][8][64]
+    unsigned *s_qpk = (unsigned *)(s_dyn + 2 * 8 * 64);        // [2][32]
+    unsigned *s_best = (unsigned *)(s_dyn + QTILE * 2);        // kcap entries (same offset as the VALU kernel: 32 KB)
+    __shared__ int s_valid;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pair = blockIdx.x;
+    const int img1 = pair, img2 = img2_base + pair;
+    const int n1 = min(kp_count[img1], kcap), n2 = min(kp_count[img2], kcap);
+    for (int i = tid; i < n1; i += MM_NT) s_best[i] = 0xFFFFFFFFu;
+    if (tid == 0) s_valid = 0;
+    const unsigned *q32 = (const unsigned *)(desc + (long long)img1 * kcap * 32);      // 8 dwords per query descriptor
+    const uint4 *d2 = (const uint4 *)(desc + (long long)img2 * kcap * 32);
+    const int ntq = (n1 + 31) >> 5, ntt = (n2 + 31) >> 5;
+    const int h = lane >> 5, col = lane & 31;
+    // this thread's share of a query tile's expansion: item = tid: K-step s = tid >> 6, lane slot l = tid & 63
+    // (row = l & 31, half = l >> 5): the 16 bits [32 s + 16 half, +16) of query (tile * 32 + row)
+    const int xs = tid >> 6, xl = tid & 63, xrow = xl & 31, xh = xl >> 5;
+    for (int tt0 = 0; tt0 < ntt && n1 > 0; tt0 += 8) {
+        const int tt = tt0 + wv;                               // wave-uniform
+        const int j = tt * 32 + col;
+        const bool valid_t = tt < ntt && j < n2;
+        // B operand of the 8 K-steps: this lane's train descriptor, bits [32 s + 16 h, +16) of step s
+        v4i_t bop[8];
+        int tpop = 0;
+        {
+            uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0;
+            if (valid_t) { t0 = d2[2 * j]; t1 = d2[2 * j + 1]; }
+            const unsigned tw[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+            for (int sK = 0; sK < 8; ++sK) { bop[sK] = expand16((tw[sK] >> (16 * h)) & 0xFFFFu); tpop += __popc(tw[sK]); }
+        }
+        unsigned best_key = 0xFFFFFFFFu;
+        // prologue: query tile 0 into buffer 0
+        unsigned nxt = 0, nxt_pop = 0;
+        auto fetch = [&](int qt) {
+            const int q = qt * 32 + xrow;
+            nxt = q < n1 ? q32[(long long)q * 8 + xs] : 0u;
+            if (tid < 32) {                                    // |q| of row tid for the packed key words
+                const int qq = qt * 32 + tid;
+                nxt_pop = 0x7000u;                             // rows past n1: a key no real distance can beat
+                if (qq < n1) {
+                    const uint4 a = ((const uint4 *)q32)[2 * qq], b = ((const uint4 *)q32)[2 * qq + 1];
+                    nxt_pop = 512u + __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+                }
+            }
+        };
+        auto stage = [&](int qt, int buf) {
+            s_a[(buf * 8 + xs) * 64 + xl] = expand16((nxt >> (16 * xh)) & 0xFFFFu);
+            if (tid < 32) s_qpk[buf * 32 + tid] = (nxt_pop << 16) | (unsigned)(qt * 32 + tid);
+        };
+        __syncthreads();                                       // the previous pass has finished reading both buffers
+        fetch(0); stage(0, 0);
+        __syncthreads();
+        for (int qt = 0; qt < ntq; ++qt) {
+            const int buf = qt & 1;
+            if (qt + 1 < ntq) fetch(qt + 1);                   // global loads of the next tile in flight during the MFMAs
+            if (tt < ntt) {
+                v16i_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int sK = 0; sK < 8; ++sK)
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(s_a[(buf * 8 + sK) * 64 + lane], bop[sK], acc, 0, 0, 0);
+                // C layout (dtype independent): column = lane & 31, row of register r = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned qpk = s_qpk[buf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+                    best_key = min(best_key, (unsigned)__mul24(acc[r], -131072) + qpk);     // (|q| + 512 - 2 q.t) << 16 | queryIdx
+                }
+            }
+            if (qt + 1 < ntq) stage(qt + 1, buf ^ 1);
+            __syncthreads();
+        }
+        best_key = min(best_key, (unsigned)__shfl_xor((int)best_key, 32));
+        if (valid_t && h == 0) {
+            const unsigned d = (best_key >> 16) - 512u + (unsigned)tpop, i = best_key & 0xFFFFu;
+            atomicMin(&s_best[i], (d << 18) | (unsigned)j);
+        }
+    }
+    __syncthreads();
+    // (dist, queryIdx) keys; unmatched queries sort to the end -- same epilogue as the VALU kernel
+    int sortP = 64;
+    while (sortP < n1) sortP <<= 1;
+    unsigned *s_key = (unsigned *)s_dyn;
+    int myvalid = 0;
+    for (int i = tid; i < sortP; i += MM_NT) {
+        unsigned key = 0xFFFFFFFFu;
+        if (i < n1) {
+            unsigned b = s_best[i];
+            if (b != 0xFFFFFFFFu) { key = ((b >> 18) << 16) | (unsigned)i; ++myvalid; }
+        }
+        s_key[i] = key;
+    }
+    if (myvalid) atomicAdd(&s_valid, myvalid);
+    __syncthreads();
+    for (int k = 2; k <= sortP; k <<= 1) {
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int t = tid; t < (sortP >> 1); t += MM_NT) {
+                int i = 2 * jj * (t / jj) + (t % jj);
+                int ixj = i + jj;
+                bool asc = (i & k) == 0;
+                unsigned a = s_key[i], b = s_key[ixj];
+                if ((a > b) == asc) { s_key[i] = b; s_key[ixj] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const int nm = min(s_valid, max_matches);
+    for (int r = tid; r < nm; r += MM_NT) {
+        unsigned key = s_key[r];
+        int i = key & 0xFFFF, d = key >> 16;
+        int j = s_best[i] & 0x3FFFF;
+        long long o = (long long)pair * max_matches + r;
+        m_q[o] = i; m_t[o] = j; m_d[o] = d;
+        pts1[o] = kp_pt[(long long)img1 * kcap + i];
+        pts2[o] = kp_pt[(long long)img2 * kcap + j];
+    }
+    if (tid == 0) m_n[pair] = nm;
+}
+
 void rpe_launch_match(rpe_handle *h, int B)
 {
     const int kcap = h->lay.kcap;
@@ -143,9 +296,13 @@ void rpe_launch_match(rpe_handle *h, int B)
         hipLaunchKernelGGL((match_hamming_kernel<true>), dim3(B), dim3(256), lds, h->stream,
                            h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches, h->cfg.match_ratio,
                            h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
-    else
+    else if (getenv("RPE_MATCH_VALU"))                    // diagnostic: the vector-ALU crossCheck kernel (A/B runs, parity tests)
         hipLaunchKernelGGL((match_hamming_kernel<false>), dim3(B), dim3(256), lds, h->stream,
                            h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches, 0.0,
+                           h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
+    else
+        hipLaunchKernelGGL(match_hamming_mfma_kernel, dim3(B), dim3(MM_NT), lds, h->stream,
+                           h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches,
                            h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
 }
 

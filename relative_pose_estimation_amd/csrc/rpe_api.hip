@@ -156,6 +156,20 @@ static int build_tables(rpe_handle *h)
         lin_coeffs(S.w, D.w, xo, xa);
         lin_coeffs(S.h, D.h, yo, ya);
     }
+    // resize tiles (128x64 destination pixels) with the origin of their source window, levels 1..11
+    {
+        std::vector<RpePyrTile> pt;
+        for (int l = 1; l < RPE_NLEVELS; ++l) {
+            const RpeLevel &S = L.lv[l - 1], &D = L.lv[l];
+            h->pyr_tile_off[l] = (int)pt.size();
+            for (int y0 = 0; y0 < D.h; y0 += 64)
+                for (int x0 = 0; x0 < D.pitch; x0 += 128)
+                    pt.push_back({(short)x0, (short)y0, (short)(((int)(((long long)x0 * S.w) / D.w)) & ~15), (short)(((long long)y0 * S.h) / D.h)});
+            h->pyr_tile_cnt[l] = (int)pt.size() - h->pyr_tile_off[l];
+        }
+        DM(h, h->d_pyr_tiles, pt.size() ? pt.size() : 1);
+        if (!pt.empty()) HIPCHK(h, hipMemcpy(h->d_pyr_tiles, pt.data(), pt.size() * sizeof(RpePyrTile), hipMemcpyHostToDevice));
+    }
     // the resize kernel stages a fixed 74-row x 176-byte source footprint per 128x64 tile (origin 16-B aligned),
     // anchored at floor(scale * tile origin); verify the tables fit it for every tile
     for (int l = 1; l < RPE_NLEVELS; ++l) {
@@ -172,20 +186,27 @@ static int build_tables(rpe_handle *h)
             if (yo[y0] < s0 || hi - s0 >= 74) { h->err = "pyramid footprint bound violated (y)"; return RPE_ERR_INVALID; }
         }
     }
-    // device form: (offset, weight) packed into one dword per destination column / row (offset < 65536, weight <= 256):
-    // the resize kernel fetches 12 table dwords per lane instead of 24.  Layout per level: [w packed x][h packed y]
-    // at coef_off (the unpacked host table keeps its 2(w+h) stride, so the offsets stay valid)
+    // device form: (offset, weight) packed into one dword per destination column / row (offset < 65536, weight <= 256).
+    // Per level: [align128(w) packed x][align64(h) packed y], padded with the last entry, every run 16-B aligned: a lane
+    // of the resize kernel fetches its 4 columns with one 16-B load and its 8 rows with two, without clamps.
     {
-        std::vector<int> packed((size_t)ncoef, 0);
+        int dtotal = 0;
+        for (int l = 1; l < RPE_NLEVELS; ++l) {
+            h->lay.lv[l].dcoef_off = dtotal;
+            dtotal += ((L.lv[l].w + 127) & ~127) + ((L.lv[l].h + 63) & ~63);
+        }
+        h->lay.lv[0].dcoef_off = 0;
+        std::vector<int> packed((size_t)dtotal + 4, 0);
         for (int l = 1; l < RPE_NLEVELS; ++l) {
             const RpeLevel &D = L.lv[l];
             const int *xo = coef.data() + D.coef_off, *xa = xo + D.w, *yo = xa + D.w, *ya = yo + D.h;
-            int *px = packed.data() + D.coef_off, *py = px + D.w;
-            for (int x = 0; x < D.w; ++x) px[x] = xo[x] | (xa[x] << 16);
-            for (int y = 0; y < D.h; ++y) py[y] = yo[y] | (ya[y] << 16);
+            const int xw = (D.w + 127) & ~127, yh = (D.h + 63) & ~63;
+            int *px = packed.data() + D.dcoef_off, *py = px + xw;
+            for (int x = 0; x < xw; ++x) { const int k = x < D.w ? x : D.w - 1; px[x] = xo[k] | (xa[k] << 16); }
+            for (int y = 0; y < yh; ++y) { const int k = y < D.h ? y : D.h - 1; py[y] = yo[k] | (ya[k] << 16); }
         }
-        DM(h, h->d_coef, ncoef);
-        HIPCHK(h, hipMemcpy(h->d_coef, packed.data(), sizeof(int) * (size_t)ncoef, hipMemcpyHostToDevice));
+        DM(h, h->d_coef, packed.size());
+        HIPCHK(h, hipMemcpy(h->d_coef, packed.data(), sizeof(int) * packed.size(), hipMemcpyHostToDevice));
     }
     // intensity-centroid disc (orb.cpp umax table)
     {
@@ -345,7 +366,7 @@ extern "C" void rpe_destroy(rpe_handle *h)
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     rpe_sift_destroy(h);
-    void *ptrs[] = {h->d_tiles_full, h->d_tiles_fast, h->d_coef, h->d_pyr, h->d_bufA, h->d_tile_list, h->d_tile_cnt, h->d_stage1, h->d_stage2,
+    void *ptrs[] = {h->d_tiles_full, h->d_tiles_fast, h->d_coef, h->d_pyr_tiles, h->d_pyr, h->d_bufA, h->d_tile_list, h->d_tile_cnt, h->d_stage1, h->d_stage2,
                     h->d_hist, h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_angle,
                     h->d_kp_pt, h->d_kp_cs, h->d_kp_count, h->d_desc, h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2,
                     h->d_subsets, h->d_nit_denom, h->d_nit_round, h->d_rstate, h->d_n1, h->d_n2, h->d_found, h->d_models, h->d_hyp, h->d_counts,

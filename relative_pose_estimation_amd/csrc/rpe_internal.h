@@ -26,7 +26,8 @@ struct RpeLevel {
     int cand_off;     // offset of this level inside per-image candidate arrays
     float scale;      // (float)pow(1.1f, l)
     long long off;    // byte offset inside the per-image pyramid buffer
-    int coef_off;     // offset of xo/xa (w entries) then yo/ya (h entries) in coef table
+    int coef_off;     // offset of xo/xa (w entries) then yo/ya (h entries) in the HOST coefficient table
+    int dcoef_off;    // device table: [align128(w) packed x][align64(h) packed y], 16-B aligned, last entry replicated
     int tile0, ntile; // this level's run inside the FAST tile table (raster order inside the level)
 };
 
@@ -39,6 +40,8 @@ struct RpeDeviceLayout {       // passed by value to kernels
 };
 
 struct RpeTile { short level, tx, ty, pad; };
+// 128x64 destination tile of the resize kernel: destination origin and origin of its source window in the level below
+struct RpePyrTile { short x0, y0, a0, sy0; };
 
 // per-pair RANSAC state in HBM
 struct RpeRansacState {
@@ -73,6 +76,8 @@ struct rpe_handle {
     RpeTile *d_tiles_full = nullptr;  int n_tiles_full = 0;   // 64x16 tiles covering every level
     RpeTile *d_tiles_fast = nullptr;  int n_tiles_fast = 0;   // tiles covering [28,w-28)x[28,h-28)
     int *d_coef = nullptr;            // resize coefficient tables
+    RpePyrTile *d_pyr_tiles = nullptr;  // resize tiles of levels 1..11, level l at pyr_tile_off[l], raster order
+    int pyr_tile_off[RPE_NLEVELS] = {}, pyr_tile_cnt[RPE_NLEVELS] = {};
     // image-shaped buffers
     uint8_t *d_pyr = nullptr;
     uint8_t *d_bufA = nullptr;        // ONE image's blurred pyramid (rpe_orb_debug_fetch only)
