@@ -33,6 +33,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 me
 # vector-instruction issue peak (MI355X_MICROARCH.md 'Wave scheduling' / cycle constants: a wave64 VALU
 # instruction takes 2 cycles on the 32-wide SIMD with >= 2 waves resident): 256 CUs x 4 SIMDs x 2.4 GHz / 2
 VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2
+# dense int8 MFMA peak: 2x the bf16 rate per clock (MI355X_MICROARCH.md 'Matrix cores'), bf16 dense ~2.5 PFLOP/s
+MFMA_I8_PEAK_TOPS = 5000.0
 COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")
 
 
@@ -108,7 +110,7 @@ def stage_bytes(stage, W, H, pyr_px, nkp, mm, method="ORB"):
 
 STAGE_KERNEL = {"pyramid": "pyr_resize_kernel", "fast": "fast_nms_kernel", "angle": "orient_describe_kernel",
                 "select": "select_candidates_kernel", "harris": "harris_kernel", "keypoints": "select_keypoints_kernel",
-                "match": "match_hamming_kernel", "ransac": "ransac_*_kernel (group)", "pose": "recover_pose_kernel"}
+                "match": "match_hamming_mfma_kernel", "ransac": "ransac_*_kernel (group)", "pose": "recover_pose_kernel"}
 # SIFT reuses the stage slots (csrc/sift_kernels.hip rpe_sift_run)
 SIFT_STAGE_KERNEL = {"pyramid": "sift_blur_fused_kernel", "fast": "sift_extrema_mask_kernel",
                      "select": "sift_adjust_kernel", "harris": "sift_orient_kernel", "keypoints": "sift_finalize_kernel",
@@ -385,6 +387,14 @@ def run_workload(args, method, sub, data, rank, world, device, comm_kind):
         dom = max(stage_ms, key=stage_ms.get)
         rl = roof(dom)
         rl["matcher"] = roof("match")              # the stage north_star attaches a roofline target to: always reported
+        if method == "ORB":
+            # the crossCheck Hamming matcher runs its O(N^2) part on the matrix cores: d = |q| + |t| - 2 q.t over 256 0/1 bytes,
+            # 32x32 tiles of v_mfma_i32_32x32x32_i8 (8 per tile); N1 = N2 = nfeatures is the algorithmic problem size
+            ops = 2.0 * 256 * args.nfeatures * args.nfeatures * Bl
+            tops = ops / (stage_ms["match"] * 1e-3) / 1e12
+            rl["matcher"]["mfma"] = {"ops": ops, "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s (int8, dense)", "frac": tops / MFMA_I8_PEAK_TOPS}
+            if rl["matcher"]["mfma"]["frac"] > max(rl["matcher"]["frac"], rl["matcher"].get("valu", {}).get("frac", 0.0)):
+                rl["matcher"]["bound"] = "mfma"
         if not args.no_calibrate:
             try:
                 rl["hbm_measured_gbs"] = eng.calibrate_hbm() / 1e9
@@ -462,6 +472,12 @@ def main():
         ast = argparse.Namespace(**vars(args))
         ast.stream, ast.cpu_sample, ast.data_cache = True, 256, ""
         extras.append(("stream", ast, "ORB", ast.batch, generate(ast, "ORB", 0, 1, workers)))
+        # the headline batch again on TWO handles (two HIP streams, half the batch each): the latency-bound RANSAC / pose
+        # kernels of one half overlap the issue-bound ORB kernels of the other.  Not the headline because per-kernel
+        # durations of overlapping streams are not clean launch times.
+        a2 = argparse.Namespace(**vars(args))
+        a2.streams, a2.no_cpu_baseline, a2.no_calibrate = 2, True, True
+        extras.append(("two_streams", a2, "ORB", a2.batch, data))
 
     from relative_pose_estimation_amd import _capi
     ndev = _capi.load().rpe_device_count()

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -o run -- python3 $R/bench.py --steps 10 --warmup 3 $B > $R/gpurun_out/${TAG}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_fetch -o run -- python3 $R/bench.py --steps 2 --warmup 1 $B > $R/gpurun_out/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_write -o run -- python3 $R/bench.py --steps 2 --warmup 1 $B > $R/gpurun_out/${TAG}_write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/${TAG}_sq -o run -- python3 $R/bench.py --steps 2 --warmup 1 $B > $R/gpurun_out/${TAG}_sq.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/${TAG}_sq -o run -- python3 $R/bench.py --steps 2 --warmup 1 $B > $R/gpurun_out/${TAG}_sq.log 2>&1
 echo done_c2
 
 # BASELINE configs[2] shape: 128 HD pairs, SIFT(2048) + L2, one launch group (16 distinct rendered pairs tiled 8x)
@@ -20,5 +20,5 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_c3_stats -o run -- python3 $R/bench.py --steps 2 --warmup 1 $B3 > $R/gpurun_out/${TAG}_c3_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_c3_fetch -o run -- python3 $R/bench.py --steps 1 --warmup 1 $B3 > $R/gpurun_out/${TAG}_c3_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_c3_write -o run -- python3 $R/bench.py --steps 1 --warmup 1 $B3 > $R/gpurun_out/${TAG}_c3_write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/${TAG}_c3_sq -o run -- python3 $R/bench.py --steps 1 --warmup 1 $B3 > $R/gpurun_out/${TAG}_c3_sq.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/${TAG}_c3_sq -o run -- python3 $R/bench.py --steps 1 --warmup 1 $B3 > $R/gpurun_out/${TAG}_c3_sq.log 2>&1
 echo done_c3

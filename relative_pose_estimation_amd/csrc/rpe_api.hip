@@ -883,8 +883,16 @@ __global__ __launch_bounds__(256) void valu_calib_kernel(unsigned *sink, int ite
 {
     unsigned a[8];
     double d[8];
+    float f[8];
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    f2_t f2[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { a[u] = threadIdx.x * 2654435761u + u * 40503u + blockIdx.x; d[u] = 1.0 + 1e-9 * (double)(a[u] & 1023u); }
+    for (int u = 0; u < 8; ++u) {
+        a[u] = threadIdx.x * 2654435761u + u * 40503u + blockIdx.x; d[u] = 1.0 + 1e-9 * (double)(a[u] & 1023u);
+        f[u] = 1.0f + 1e-6f * (float)(a[u] & 1023u); f2[u].x = f[u]; f2[u].y = f[u] * 0.5f;
+    }
+    const float fk = 1.0000001f;
+    const f2_t fk2 = {1.0000001f, 0.9999999f};
     const unsigned k0 = 0x9E3779B9u ^ threadIdx.x, k1 = 0x01010101u;
     const double dk = 1.0000000001;
     for (int it = 0; it < iters; ++it) {
@@ -906,25 +914,29 @@ __global__ __launch_bounds__(256) void valu_calib_kernel(unsigned *sink, int ite
                     asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[u]) : "v"(k1), "v"(k0));
                 else if (KIND == 6)  // RANSAC / pose: v_mul_f64 + v_add_f64 (2 instructions; the library compiles without contraction)
                     asm volatile("v_mul_f64 %0, %0, %1\n\tv_add_f64 %0, %0, %1" : "+v"(d[u]) : "v"(dk));
-                else                 // v_fma_f64 (1 instruction), for reference
+                else if (KIND == 7)  // v_fma_f64 (1 instruction), for reference
                     asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d[u]) : "v"(dk));
+                else if (KIND == 8)  // v_fma_f32 (1 instruction): the guide's 2-cycle instruction
+                    asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[u]) : "v"(fk));
+                else                 // v_pk_fma_f32 (1 instruction, 2 FMAs per lane): the 157 TFLOP/s f32 vector peak
+                    asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(f2[u]) : "v"(fk2));
             }
         }
     }
     unsigned acc = 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc ^= a[u] ^ (unsigned)__double_as_longlong(d[u]);
+    for (int u = 0; u < 8; ++u) acc ^= a[u] ^ (unsigned)__double_as_longlong(d[u]) ^ __float_as_uint(f[u]) ^ __float_as_uint(f2[u].x) ^ __float_as_uint(f2[u].y);
     if (acc == 0x12345679u) *sink = acc;
 }
 
-static const int kCalibInstPerSlot[8] = {2, 2, 1, 1, 2, 1, 2, 1};
-static const char *kCalibNames[8] = {"v_xor_b32+v_bcnt_u32_b32", "v_pk_min_i16+v_pk_max_i16", "v_perm_b32", "v_dot4_u32_u8",
-                                     "v_min3_i32+v_max3_i32", "v_mad_u32_u24", "v_mul_f64+v_add_f64", "v_fma_f64"};
-extern "C" const char *rpe_calibrate_valu_name(int kind) { return (kind >= 0 && kind < 8) ? kCalibNames[kind] : "?"; }
+static const int kCalibInstPerSlot[10] = {2, 2, 1, 1, 2, 1, 2, 1, 1, 1};
+static const char *kCalibNames[10] = {"v_xor_b32+v_bcnt_u32_b32", "v_pk_min_i16+v_pk_max_i16", "v_perm_b32", "v_dot4_u32_u8",
+                                      "v_min3_i32+v_max3_i32", "v_mad_u32_u24", "v_mul_f64+v_add_f64", "v_fma_f64", "v_fma_f32", "v_pk_fma_f32"};
+extern "C" const char *rpe_calibrate_valu_name(int kind) { return (kind >= 0 && kind < 10) ? kCalibNames[kind] : "?"; }
 
 extern "C" int rpe_calibrate_valu(rpe_handle *h, int kind, int waves_per_simd, double *wave_insts_per_s)
 {
-    if (!h || !wave_insts_per_s || kind < 0 || kind > 7 || waves_per_simd < 1 || waves_per_simd > 8) return RPE_ERR_INVALID;
+    if (!h || !wave_insts_per_s || kind < 0 || kind > 9 || waves_per_simd < 1 || waves_per_simd > 8) return RPE_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, h->cfg.device));
@@ -939,6 +951,7 @@ extern "C" int rpe_calibrate_valu(rpe_handle *h, int kind, int waves_per_simd, d
         switch (kind) {
 #define CALIB_CASE(K) case K: hipLaunchKernelGGL((valu_calib_kernel<K>), dim3(blocks), dim3(256), 0, h->stream, (unsigned *)h->d_hist, iters); break;
             CALIB_CASE(0) CALIB_CASE(1) CALIB_CASE(2) CALIB_CASE(3) CALIB_CASE(4) CALIB_CASE(5) CALIB_CASE(6) CALIB_CASE(7)
+            CALIB_CASE(8) CALIB_CASE(9)
 #undef CALIB_CASE
         }
         HIPCHK(h, hipEventRecord(e1, h->stream));

@@ -304,3 +304,18 @@ def test_native_pose_gather_world1(capi, K_vga):
     comm.barrier()
     comm.close()
     e.close()
+
+
+# ------------------------------------------------------------------ roofline calibration entry points
+def test_calibration_entry_points(capi):
+    """rpe_calibrate_valu / rpe_calibrate_hbm run and give physically possible rates: integer and f64 instructions issue
+    at most once per 2 cycles per SIMD (1.23e12 wave-instructions/s at 2.4 GHz), HBM reads below the 8 TB/s spec peak"""
+    e = capi.Engine(640, 480, max_batch=512, nfeatures=1000)          # 1.6 GB of pyramid: larger than the Infinity Cache
+    for kind in (0, 4, 6):
+        name, rate = e.calibrate_valu(kind, 8)
+        assert name and 1e11 < rate < 1.3e12, (name, rate)
+    name1, r1 = e.calibrate_valu(0, 1)
+    assert r1 <= e.calibrate_valu(0, 8)[1] * 1.05                     # one wave per SIMD never beats eight
+    bw = e.calibrate_hbm()
+    assert 1e12 < bw < 8e12, bw
+    e.close()
