@@ -824,8 +824,10 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
         // ---- horizontal pass: hbuf column j <-> x = x0 - 19 + j (40 per row; the descriptor
         // reaches |dx| <= 18), 4 outputs per work item.  Output j of group gq needs raw bytes
         // bo + j .. bo + j + 6 with bo = off0 + 4*gq (>= 0).
-        for (int i = lane; i < KP_ROWS * 10; i += 64) {
-            const int r = i / 10, gq = i - r * 10;
+        // rows 1 .. 43 only: the steered samples reach |dy| <= 18 and the vertical taps 3 more (rows 22 - 21 .. 22 + 21);
+        // 430 items = 7 wave rounds instead of the 8 that 45 rows need
+        for (int i = lane; i < (KP_ROWS - 2) * 10; i += 64) {
+            const int r = 1 + i / 10, gq = i - (r - 1) * 10;
             const int bo = off0 + 4 * gq, d0 = bo >> 2, sh = bo & 3;
             const unsigned *rw = raw + r * KP_RAW_DW;
             const unsigned w0 = rw[d0], w1 = rw[d0 + 1], w2 = rw[min(d0 + 2, KP_RAW_DW - 1)], w3 = rw[min(d0 + 3, KP_RAW_DW - 1)];
