@@ -30,6 +30,12 @@ __constant__ signed char c_circ[16 * 2] = {0,3, 1,3, 2,2, 3,1, 3,0, 3,-1, 2,-2, 
 // .x = 1 per in-disc byte, .y = (u + 16) per in-disc byte (0 elsewhere)
 __constant__ uint2 c_discw[31 * 8];
 
+// B operand of the horizontal Gaussian pass as an i8 MFMA (orient_describe_kernel): [off0 0..3][K-step 0..1][column tile 0..1][lane]
+// 16 bytes each = T[32 s + 16 (lane >> 5) + b][32 nt + (lane & 31)], T[k][j] = tap[k - off0 - j]
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+__device__ v4i_t c_blur_b[4 * 2 * 2 * 64];
+
 void rpe_orb_upload_disc(const signed char *disc, int n)
 {
     hipMemcpyToSymbol(HIP_SYMBOL(c_disc), disc, (size_t)n * 2);
@@ -43,6 +49,18 @@ void rpe_orb_upload_disc(const signed char *disc, int n)
         wt[(v + 15) * 8 + j].y |= (unsigned)(u + 16) << (8 * b);
     }
     hipMemcpyToSymbol(HIP_SYMBOL(c_discw), wt, sizeof(wt));
+    // banded tap matrix of the 7x7 Gaussian's horizontal pass, in MFMA B-operand order
+    static const signed char tap[7] = {18, 34, 49, 55, 49, 34, 18};
+    std::vector<signed char> tb((size_t)4 * 2 * 2 * 64 * 16, 0);
+    for (int off0 = 0; off0 < 4; ++off0)
+        for (int s = 0; s < 2; ++s)
+            for (int nt = 0; nt < 2; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int b = 0; b < 16; ++b) {
+                        const int k = 32 * s + 16 * (lane >> 5) + b, j = 32 * nt + (lane & 31), d = k - off0 - j;
+                        if (k < 48 && d >= 0 && d <= 6) tb[((((size_t)off0 * 2 + s) * 2 + nt) * 64 + lane) * 16 + b] = tap[d];
+                    }
+    hipMemcpyToSymbol(HIP_SYMBOL(c_blur_b), tb.data(), tb.size());
 }
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an
@@ -758,16 +776,19 @@ void rpe_launch_keypoints(rpe_handle *h, int n_img)
 #define KP_ROWS 45
 #define KP_RAW_DW 12                 // 48 bytes per raw row
 #define KP_H_DW 20                   // 40 u16 per horizontally blurred row
+#define KP_HROWS 48                  // rows of the horizontally blurred buffer (45 + 3 of padding for the unpredicated MFMA tile stores)
 __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__restrict__ pyr, const unsigned *__restrict__ kp_xy,
                                                                const float2 *__restrict__ kp_pt, const int *__restrict__ kp_count,
                                                                float *__restrict__ kp_angle, uint8_t *__restrict__ desc,
                                                                RpeDeviceLayout lay)
 {
-    __shared__ unsigned s_raw[4][KP_ROWS * KP_RAW_DW];
-    __shared__ unsigned s_hb[4][KP_ROWS * KP_H_DW];
+    __shared__ __attribute__((aligned(16))) unsigned s_raw[4][KP_ROWS * KP_RAW_DW];   // 2160 B per wave: 16-B aligned rows of 48 B
+    __shared__ unsigned s_hb[4][KP_HROWS * KP_H_DW];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int k = blockIdx.x * 4 + wv, img = blockIdx.y;
-    const bool active = k < kp_count[img];
+    const int nkp = kp_count[img];
+    if (blockIdx.x * 4 >= nkp) return;                        // workgroup-uniform: the grid is sized for the keypoint capacity
+    const bool active = k < nkp;
     const long long g = (long long)img * lay.kcap + (active ? k : 0);
     const unsigned p = kp_xy[g];
     const int x0 = p & 0xFFF, y0 = (p >> 12) & 0xFFF, l = p >> 24;
@@ -821,28 +842,49 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
         double sn, cs;
         det_sincos((double)ang, sn, cs);
         a = (float)cs; b = (float)sn;
-        // ---- horizontal pass: hbuf column j <-> x = x0 - 19 + j (40 per row; the descriptor
-        // reaches |dx| <= 18), 4 outputs per work item.  Output j of group gq needs raw bytes
-        // bo + j .. bo + j + 6 with bo = off0 + 4*gq (>= 0).
-        // rows 1 .. 43 only: the steered samples reach |dy| <= 18 and the vertical taps 3 more (rows 22 - 21 .. 22 + 21);
-        // 430 items = 7 wave rounds instead of the 8 that 45 rows need
-        for (int i = lane; i < (KP_ROWS - 2) * 10; i += 64) {
-            const int r = 1 + i / 10, gq = i - (r - 1) * 10;
-            const int bo = off0 + 4 * gq, d0 = bo >> 2, sh = bo & 3;
-            const unsigned *rw = raw + r * KP_RAW_DW;
-            const unsigned w0 = rw[d0], w1 = rw[d0 + 1], w2 = rw[min(d0 + 2, KP_RAW_DW - 1)], w3 = rw[min(d0 + 3, KP_RAW_DW - 1)];
-            const unsigned q0 = __builtin_amdgcn_alignbyte(w1, w0, sh), q1 = __builtin_amdgcn_alignbyte(w2, w1, sh),
-                           q2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
-            // taps [18,34,49,55 | 49,34,18,0] = cvRound(256 g_i) (sum 257: a row sum still fits 16 bits, 255 * 257 = 65535)
-            // as two packed-u8 dot products per output (v_dot4_u32_u8)
-            const unsigned W0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), W1 = 49u | (34u << 8) | (18u << 16);
-            unsigned o[4];
-            o[0] = __builtin_amdgcn_udot4(q1, W1, __builtin_amdgcn_udot4(q0, W0, 0u, false), false);
-            o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(q2, q1, 1), W1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(q1, q0, 1), W0, 0u, false), false);
-            o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(q2, q1, 2), W1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(q1, q0, 2), W0, 0u, false), false);
-            o[3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(q2, q1, 3), W1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(q1, q0, 3), W0, 0u, false), false);
-            hb[r * KP_H_DW + 2 * gq] = o[0] | (o[1] << 16);
-            hb[r * KP_H_DW + 2 * gq + 1] = o[2] | (o[3] << 16);
+        // ---- horizontal pass on the matrix cores: hbuf column j <-> x = x0 - 19 + j (40 per row; the descriptor reaches
+        // |dx| <= 18).  H[45 x 40] = P[45 x 48 raw bytes] . T[48 x 40] with the banded tap matrix T[k][j] = tap[k - off0 - j]
+        // (tap = cvRound(256 g) = 18,34,49,55,49,34,18): 2 x 2 output tiles x 2 K-steps of v_mfma_i32_32x32x32_i8, exact
+        // integers.  The u8 pixels enter as signed bytes (p - 128, one v_xor per dword) and the accumulators start at
+        // 128 * 257, the tap sum's share of the offset.  The pass used to be 430 items x ~33 vector instructions (two
+        // v_dot4 per output plus the byte alignment) = 30 % of this issue-bound kernel; now the vector ALU only flips the
+        // sign bits.  Accumulators go to LDS as u16 (<= 65535 = 255 * 257) with immediate-offset ds_write_b16.
+        {
+            const int hh = lane >> 5, c32 = lane & 31;
+            const uint8_t *rawb = (const uint8_t *)raw;
+            unsigned short *hb16 = (unsigned short *)hb;
+            v4i_t bop[2][2];
+#pragma unroll
+            for (int sK = 0; sK < 2; ++sK)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) bop[sK][nt] = c_blur_b[((off0 * 2 + sK) * 2 + nt) * 64 + lane];
+            v16i_t cinit;                                       // loop-invariant C operand: 128 * (tap sum) in every element
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cinit[r] = 128 * 257;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int arow = min(32 * mt + c32, KP_ROWS - 1);
+                v4i_t a0 = *(const v4i_t *)(rawb + arow * (KP_RAW_DW * 4) + 16 * hh);          // K-step 0: row bytes [16 hh, +16)
+                v4i_t a1 = {0, 0, 0, 0};                                                       // K-step 1: bytes [32 + 16 hh, +16), 48 per row
+                if (hh == 0) a1 = *(const v4i_t *)(rawb + arow * (KP_RAW_DW * 4) + 32);
+                a0 ^= (int)0x80808080; a1 ^= (int)0x80808080;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    v16i_t acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bop[0][nt], cinit, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bop[1][nt], acc, 0, 0, 0);
+                    const int colj = 32 * nt + c32;
+                    if (colj < KP_H_DW * 2) {
+                        // C layout: register r holds row (r & 3) + 8 (r >> 2) + 4 hh of the tile: one per-lane base, immediate
+                        // offsets, no per-store predicate (rows 45..47 exist as padding; rows >= 48 are skipped statically)
+                        unsigned short *dst = hb16 + (32 * mt + 4 * hh) * (KP_H_DW * 2) + colj;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rb = (r & 3) + 8 * (r >> 2);
+                            if (32 * mt + rb + 4 < KP_HROWS) dst[rb * (KP_H_DW * 2)] = (unsigned short)acc[r];
+                        }
+                    }
+                }
+            }
         }
     }
     __syncthreads();
