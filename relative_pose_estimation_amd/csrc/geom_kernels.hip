@@ -185,9 +185,10 @@ __device__ __forceinline__ double refine_root_s(const double (&p)[11], const dou
 
 // Nister five-point solver (five-point.cpp EMEstimatorCallback::runKernel restated;
 // same operation order as oracle/geom_oracle.c)
-// mx: this lane's 10x20 elimination matrix in LDS, element (i,j) at mx[(i*20+j)*64]
+// mx: this lane's 10x20 elimination matrix in LDS, element (i,j) at mx[(i*20+j)*POLY_LANES]
 // (lane-interleaved: conflict-free ds_read/write_b64, no scratch round trips)
-#define MX(i, j) mx[((i) * 20 + (j)) * 64]
+#define POLY_LANES 32        // minimal samples per wave of ransac_poly_kernel (lanes 32..63 idle): see the kernel
+#define MX(i, j) mx[((i) * 20 + (j)) * POLY_LANES]
 // Part A of the solver (LDS-heavy): null space, constraint matrix, Gauss-Jordan, det B(z).
 // Writes the hypothesis record rec[k*64] (k = 0..86): c10[11], Bx[12], By[12], B1[15], Eb[36], degree n;
 // returns 0 when the elimination is singular.
@@ -356,15 +357,19 @@ __global__ __launch_bounds__(256) void ransac_prepare_kernel(const float2 *__res
 }
 
 // ------------------------------------------------------------------ solve
-// A: one wave per (pair, 64 iterations); 100 KB of LDS per wave => one wave per CU
-__global__ __launch_bounds__(64) void ransac_poly_kernel(const double2 *__restrict__ n1, const double2 *__restrict__ n2,
-                                                          const RpeRansacState *__restrict__ st,
-                                                          const unsigned short *__restrict__ subsets,
-                                                          double *__restrict__ hyp, int *__restrict__ nmodels,
-                                                          int max_matches, int max_iters)
+// A: one wave per (pair, 32 iterations), 32 active lanes.  The 10x20 elimination lives in LDS (1600 B per sample); the
+// kernel retires 0.015 G vector instructions in 0.44 ms -- 3 % of the issue roof: it is pure single-wave latency, and a
+// full 64-sample wave (100 KB) fits a CU only once.  Half-filled waves (50 KB) fit three times: three latency chains per
+// CU instead of one (the idle lanes cost nothing a latency-bound kernel would have used).
+__global__ __launch_bounds__(POLY_LANES) void ransac_poly_kernel(const double2 *__restrict__ n1, const double2 *__restrict__ n2,
+                                                                  const RpeRansacState *__restrict__ st,
+                                                                  const unsigned short *__restrict__ subsets,
+                                                                  double *__restrict__ hyp, int *__restrict__ nmodels,
+                                                                  int max_matches, int max_iters)
 {
-    __shared__ double s_mx[200 * 64];
-    const int pair = blockIdx.x, wv = blockIdx.y, lane = threadIdx.x;
+    __shared__ double s_mx[200 * POLY_LANES];
+    // blockIdx.y = wave-chunk of 64 iterations * (64 / POLY_LANES) + part: lanes of this block = samples part*POLY_LANES .. of the chunk
+    const int pair = blockIdx.x, wv = blockIdx.y / (64 / POLY_LANES), lane = (blockIdx.y % (64 / POLY_LANES)) * POLY_LANES + threadIdx.x;
     const RpeRansacState s = st[pair];
     if (s.done) return;
     const int it = s.next_iter + wv * 64 + lane;
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(64) void ransac_poly_kernel(const double2 *__restri
             double2 a = n1[(long long)pair * max_matches + v], b = n2[(long long)pair * max_matches + v];
             x1[2 * k] = a.x; x1[2 * k + 1] = a.y; x2[2 * k] = b.x; x2[2 * k + 1] = b.y;
         }
-        ok = five_point_poly(x1, x2, s_mx + lane, hyp + ((long long)pair * (RPE_RANSAC_MAXCHUNK / 64) + wv) * HYP_DOUBLES * 64 + lane);
+        ok = five_point_poly(x1, x2, s_mx + threadIdx.x, hyp + ((long long)pair * (RPE_RANSAC_MAXCHUNK / 64) + wv) * HYP_DOUBLES * 64 + lane);
     }
     nmodels[slot] = ok ? -1 : 0;          // -1: record valid, roots pending
 }
@@ -809,7 +814,7 @@ void rpe_launch_ransac(rpe_handle *h, int B, bool want_mask)
     int done_iters = 0, chunk = 64, nlaunch = 0;
     while (done_iters < it) {
         const int wpp = chunk / 64;
-        hipLaunchKernelGGL(ransac_poly_kernel, dim3(B, wpp), dim3(64), 0, h->stream,
+        hipLaunchKernelGGL(ransac_poly_kernel, dim3(B, wpp * (64 / POLY_LANES)), dim3(POLY_LANES), 0, h->stream,
                            n1, n2, h->d_rstate, h->d_subsets, h->d_hyp, h->d_nmodels, mm, it);
         hipLaunchKernelGGL(ransac_roots_kernel, dim3(B * wpp * (64 * RG / 256)), dim3(256), 0, h->stream,
                            (const RpeRansacState *)h->d_rstate, (const double *)h->d_hyp, h->d_models, h->d_nmodels, B, wpp);
