@@ -73,6 +73,20 @@ __device__ __forceinline__ int xcd_tile(int b, int n)
     return (b & 7) * per + (b >> 3);
 }
 
+// Image-granular XCD mapping for the per-keypoint / per-candidate gather kernels: workgroups are dealt round-robin over
+// the 8 XCDs (b and b + 8 share one), each XCD has its own 4 MB L2, and a gather kernel whose workgroups of ONE image
+// land on all 8 XCDs pulls that image's pyramid into 8 L2s (r02 PMC: 8.75 GB fetched per step by the descriptor kernel
+// for 3.3 GB of pyramids).  Linear block b -> XCD group x = b % 8, position idx = b / 8 inside the group; group x owns
+// images x, x + 8, ... and walks them one after the other: img = x + 8 (idx / nb), blk = idx % nb.  Speed / traffic only.
+__device__ __forceinline__ bool xcd_image_block(int nb, int n_img, int &img, int &blk)
+{
+    const int b = blockIdx.x, x = b & 7, idx = b >> 3;
+    img = x + 8 * (idx / nb);
+    blk = idx - (idx / nb) * nb;
+    return img < n_img;
+}
+static inline unsigned xcd_image_grid(int nb, int n_img) { return (unsigned)(8 * ((n_img + 7) / 8) * nb); }
+
 // ---------------------------------------------------------------- pyramid
 // Workgroup = 128x64 destination tile of level l.  The source footprint in level l-1
 // (<= 74 rows x 152 bytes, bounds derived arithmetically so the loads do not depend on
@@ -588,11 +602,13 @@ void rpe_launch_select(rpe_handle *h, int n_img)
 // orb.cpp HarrisResponses: 7x7 block of 3x3 Sobel-like derivatives, f32 response.
 __global__ __launch_bounds__(256) void harris_kernel(const uint8_t *__restrict__ pyr, const unsigned *__restrict__ cand_xy,
                                                       const int *__restrict__ cand_count, float *__restrict__ cand_resp,
-                                                      RpeDeviceLayout lay)
+                                                      RpeDeviceLayout lay, int nb, int n_img)
 {
     // dense lane -> candidate mapping over the per-level counts: the slot arrays are sized 4*quota + 256 per level but
     // hold ~2*quota entries, so slot-indexed lanes were two thirds idle
-    const int dsel = blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
+    int img, blk;
+    if (!xcd_image_block(nb, n_img, img, blk)) return;
+    const int dsel = blk * 256 + threadIdx.x;
     int l = -1, ci = 0, acc = 0;
 #pragma unroll
     for (int k = 0; k < RPE_NLEVELS; ++k) {
@@ -650,8 +666,9 @@ __global__ __launch_bounds__(256) void harris_kernel(const uint8_t *__restrict__
 
 void rpe_launch_harris(rpe_handle *h, int n_img)
 {
-    hipLaunchKernelGGL(harris_kernel, dim3((h->lay.cand_total + 255) / 256, n_img), dim3(256), 0, h->stream,
-                       h->d_pyr, h->d_cand_xy, h->d_cand_count, h->d_cand_resp, h->lay);
+    const int nb = (h->lay.cand_total + 255) / 256;
+    hipLaunchKernelGGL(harris_kernel, dim3(xcd_image_grid(nb, n_img)), dim3(256), 0, h->stream,
+                       h->d_pyr, h->d_cand_xy, h->d_cand_count, h->d_cand_resp, h->lay, nb, n_img);
 }
 
 // -------------------------------------------------------------- keypoints
@@ -780,14 +797,16 @@ void rpe_launch_keypoints(rpe_handle *h, int n_img)
 __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__restrict__ pyr, const unsigned *__restrict__ kp_xy,
                                                                const float2 *__restrict__ kp_pt, const int *__restrict__ kp_count,
                                                                float *__restrict__ kp_angle, uint8_t *__restrict__ desc,
-                                                               RpeDeviceLayout lay)
+                                                               RpeDeviceLayout lay, int nb, int n_img)
 {
     __shared__ __attribute__((aligned(16))) unsigned s_raw[4][KP_ROWS * KP_RAW_DW];   // 2160 B per wave: 16-B aligned rows of 48 B
     __shared__ unsigned s_hb[4][KP_HROWS * KP_H_DW];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int k = blockIdx.x * 4 + wv, img = blockIdx.y;
+    int img, blk;
+    if (!xcd_image_block(nb, n_img, img, blk)) return;
+    const int k = blk * 4 + wv;
     const int nkp = kp_count[img];
-    if (blockIdx.x * 4 >= nkp) return;                        // workgroup-uniform: the grid is sized for the keypoint capacity
+    if (blk * 4 >= nkp) return;                               // workgroup-uniform: the grid is sized for the keypoint capacity
     const bool active = k < nkp;
     const long long g = (long long)img * lay.kcap + (active ? k : 0);
     const unsigned p = kp_xy[g];
@@ -921,8 +940,9 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
 
 void rpe_launch_angle(rpe_handle *h, int n_img)
 {
-    hipLaunchKernelGGL(orient_describe_kernel, dim3((h->lay.kcap + 3) / 4, n_img), dim3(256), 0, h->stream,
-                       h->d_pyr, h->d_kp_xy, h->d_kp_pt, h->d_kp_count, h->d_kp_angle, h->d_desc, h->lay);
+    const int nb = (h->lay.kcap + 3) / 4;
+    hipLaunchKernelGGL(orient_describe_kernel, dim3(xcd_image_grid(nb, n_img)), dim3(256), 0, h->stream,
+                       h->d_pyr, h->d_kp_xy, h->d_kp_pt, h->d_kp_count, h->d_kp_angle, h->d_desc, h->lay, nb, n_img);
 }
 
 // ------------------------------------------------------------------- blur
