@@ -187,6 +187,7 @@ __device__ __forceinline__ double refine_root_s(const double (&p)[11], const dou
 // same operation order as oracle/geom_oracle.c)
 // mx: this lane's 10x20 elimination matrix in LDS, element (i,j) at mx[(i*20+j)*POLY_LANES]
 // (lane-interleaved: conflict-free ds_read/write_b64, no scratch round trips)
+#define SCORE_GROUP 16       // iterations scored by one workgroup of ransac_score_kernel
 #define POLY_LANES 32        // minimal samples per wave of ransac_poly_kernel (lanes 32..63 idle): see the kernel
 #define MX(i, j) mx[((i) * 20 + (j)) * POLY_LANES]
 // Part A of the solver (LDS-heavy): null space, constraint matrix, Gauss-Jordan, det B(z).
@@ -599,7 +600,9 @@ __device__ __forceinline__ int update_niters(const double *nit_denom, const int 
 }
 
 // ------------------------------------------------------------------ score
-// One workgroup per (pair, group of 64 iterations).  The K-normalised matches sit in LDS; each of
+// One workgroup per (pair, group of SCORE_GROUP iterations): a wave scores its models one after the other, so the group
+// size sets the kernel's latency (the later RANSAC rounds run few pairs and are pure latency): 16 iterations per
+// workgroup = 4x the workgroups of the 64-iteration grouping, each a quarter as long.  The K-normalised matches sit in LDS; each of
 // the 4 waves scores a different model (lanes stride over the matches, Sampson error f64 -> f32
 // compare, wave-shuffle popcount), so there is no cross-wave reduction.  Counts go to HBM.
 __global__ __launch_bounds__(256) void ransac_score_kernel(const double2 *__restrict__ n1, const double2 *__restrict__ n2,
@@ -608,10 +611,10 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const double2 *__rest
                                                             double threshold, int *__restrict__ counts, int max_matches, int use_lds)
 {
     extern __shared__ double2 s_pts[];              // [2][max_matches] when the points fit LDS (use_lds)
-    __shared__ int s_nm[64], s_first[65];
+    __shared__ int s_nm[SCORE_GROUP], s_first[SCORE_GROUP + 1];
     const int pair = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const RpeRansacState s = st[pair];
-    if (s.done || s.M <= 5 || s.next_iter + grp * 64 >= s.niters) return;
+    if (s.done || s.M <= 5 || s.next_iter + grp * SCORE_GROUP >= s.niters) return;
     const int M = s.M;
     // max_matches > 2048 ("no truncation" configurations): 32 B per match no longer fit the 64 KB of dynamic LDS;
     // the points are then read from HBM / L2 directly (every wave walks the same 64 KB-scale array)
@@ -621,16 +624,16 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const double2 *__rest
         for (int i = tid; i < M; i += 256) { l1[i] = sp1[i]; l2[i] = sp2[i]; }
         sp1 = l1; sp2 = l2;
     }
-    const long long slot0 = (long long)pair * RPE_RANSAC_MAXCHUNK + grp * 64;
-    if (tid < 64) s_nm[tid] = nmodels[slot0 + tid];
+    const long long slot0 = (long long)pair * RPE_RANSAC_MAXCHUNK + grp * SCORE_GROUP;
+    if (tid < SCORE_GROUP) s_nm[tid] = max(nmodels[slot0 + tid], 0);
     __syncthreads();
-    if (tid == 0) { int acc = 0; for (int k = 0; k < 64; ++k) { s_first[k] = acc; acc += s_nm[k]; } s_first[64] = acc; }
+    if (tid == 0) { int acc = 0; for (int k = 0; k < SCORE_GROUP; ++k) { s_first[k] = acc; acc += s_nm[k]; } s_first[SCORE_GROUP] = acc; }
     __syncthreads();
     const double fx = K[0], fy = K[4];
     const double thr = threshold / ((fx + fy) / 2);
     const float thr2 = (float)(thr * thr);
     const SampsonBound sbound = sampson_bound(thr2);
-    const int total = s_first[64];
+    const int total = s_first[SCORE_GROUP];
     // a wave scores models j = wv, wv + 4, ... one after the other; the 72 bytes of the NEXT model are fetched (lanes 0..8,
     // one double each) before the current one is scored, so the HBM / L2 round trip of the model hides behind ~400
     // instructions of Sampson arithmetic instead of heading every iteration (the kernel ran at 28 % of its issue roof)
@@ -818,7 +821,7 @@ void rpe_launch_ransac(rpe_handle *h, int B, bool want_mask)
                            n1, n2, h->d_rstate, h->d_subsets, h->d_hyp, h->d_nmodels, mm, it);
         hipLaunchKernelGGL(ransac_roots_kernel, dim3(B * wpp * (64 * RG / 256)), dim3(256), 0, h->stream,
                            (const RpeRansacState *)h->d_rstate, (const double *)h->d_hyp, h->d_models, h->d_nmodels, B, wpp);
-        hipLaunchKernelGGL(ransac_score_kernel, dim3(B, wpp), dim3(256), lds, h->stream,
+        hipLaunchKernelGGL(ransac_score_kernel, dim3(B, wpp * (64 / SCORE_GROUP)), dim3(256), lds, h->stream,
                            n1, n2, (const RpeRansacState *)h->d_rstate, (const double *)h->d_models, (const int *)h->d_nmodels,
                            (const double *)h->d_K, h->cfg.ransac_threshold, h->d_counts, mm, use_lds);
         hipLaunchKernelGGL(ransac_update_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream,

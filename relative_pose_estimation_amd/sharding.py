@@ -58,7 +58,9 @@ def pack_records(R, t, inliers, status, n_matches, first_pair=0):
 
 # ----------------------------------------------------------------------------- native RCCL path (no torch)
 def _id_path(tag=None):
-    tag = tag or "{}_{}".format(os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"))
+    # MASTER_PORT + run id + the launcher's pid (every rank is a child of the same torch.distributed.run agent): a file
+    # left behind by a crashed earlier launch on the same port can never be mistaken for this launch's id
+    tag = "{}_{}_{}_{}".format(os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid(), tag or "")
     return os.path.join(os.environ.get("RPE_COMM_DIR", "/tmp"), f"rpe_comm_{tag}.id")
 
 
