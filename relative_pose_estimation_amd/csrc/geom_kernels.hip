@@ -187,7 +187,7 @@ __device__ __forceinline__ double refine_root_s(const double (&p)[11], const dou
 // same operation order as oracle/geom_oracle.c)
 // mx: this lane's 10x20 elimination matrix in LDS, element (i,j) at mx[(i*20+j)*POLY_LANES]
 // (lane-interleaved: conflict-free ds_read/write_b64, no scratch round trips)
-#define SCORE_GROUP 16       // iterations scored by one workgroup of ransac_score_kernel
+#define SCORE_GROUP 8       // iterations scored by one workgroup of ransac_score_kernel
 #define POLY_LANES 32        // minimal samples per wave of ransac_poly_kernel (lanes 32..63 idle): see the kernel
 #define MX(i, j) mx[((i) * 20 + (j)) * POLY_LANES]
 // Part A of the solver (LDS-heavy): null space, constraint matrix, Gauss-Jordan, det B(z).
