@@ -792,15 +792,19 @@ void rpe_launch_keypoints(rpe_handle *h, int n_img)
 #define KP_R 22
 #define KP_ROWS 45
 #define KP_RAW_DW 12                 // 48 bytes per raw row
-#define KP_H_DW 20                   // 40 u16 per horizontally blurred row
-#define KP_HROWS 48                  // rows of the horizontally blurred buffer (45 + 3 of padding for the unpredicated MFMA tile stores)
+#define KP_HCOLS 40                  // horizontally blurred columns: x = x0 - 19 + j
+#define KP_HROWS 48                  // rows per column of the blurred buffer (45 + 3 of padding for the unpredicated MFMA tile stores)
+#define KP_HSTRIDE 52                // u16 per column (104 B: 48 rows + 8 B; 26 dwords, so the 16 lanes of a ds_write_b64 group hit 16 distinct bank pairs)
 __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__restrict__ pyr, const unsigned *__restrict__ kp_xy,
                                                                const float2 *__restrict__ kp_pt, const int *__restrict__ kp_count,
                                                                float *__restrict__ kp_angle, uint8_t *__restrict__ desc,
                                                                RpeDeviceLayout lay, int nb, int n_img)
 {
     __shared__ __attribute__((aligned(16))) unsigned s_raw[4][KP_ROWS * KP_RAW_DW];   // 2160 B per wave: 16-B aligned rows of 48 B
-    __shared__ unsigned s_hb[4][KP_HROWS * KP_H_DW];
+    // horizontally blurred patch, COLUMN-major u16 [column][row]: the 7 vertical taps of a steered sample are 14
+    // contiguous bytes (three aligned ds_read_b64 instead of seven bank-conflicting ds_read_u16), and an MFMA lane, which
+    // owns one column and 4 consecutive rows per register group, stores 8 bytes at a time
+    __shared__ __attribute__((aligned(8))) unsigned s_hb[4][KP_HCOLS * KP_HSTRIDE / 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int img, blk;
     if (!xcd_image_block(nb, n_img, img, blk)) return;
@@ -892,14 +896,19 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
                     v16i_t acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bop[0][nt], cinit, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bop[1][nt], acc, 0, 0, 0);
                     const int colj = 32 * nt + c32;
-                    if (colj < KP_H_DW * 2) {
-                        // C layout: register r holds row (r & 3) + 8 (r >> 2) + 4 hh of the tile: one per-lane base, immediate
-                        // offsets, no per-store predicate (rows 45..47 exist as padding; rows >= 48 are skipped statically)
-                        unsigned short *dst = hb16 + (32 * mt + 4 * hh) * (KP_H_DW * 2) + colj;
+                    if (colj < KP_HCOLS) {
+                        // C layout: registers 4 g .. 4 g + 3 hold rows 8 g + 4 hh .. + 3 of the tile, this lane's column:
+                        // four u16 = one ds_write_b64 per group (rows 45..47 exist as padding, groups from row 48 on are
+                        // skipped statically)
+                        unsigned short *dst = hb16 + colj * KP_HSTRIDE + 32 * mt + 4 * hh;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int rb = (r & 3) + 8 * (r >> 2);
-                            if (32 * mt + rb + 4 < KP_HROWS) dst[rb * (KP_H_DW * 2)] = (unsigned short)acc[r];
+                        for (int gq = 0; gq < 4; ++gq) {
+                            if (32 * mt + 8 * gq + 4 < KP_HROWS) {
+                                uint2 pk;
+                                pk.x = ((unsigned)acc[4 * gq] & 0xFFFFu) | ((unsigned)acc[4 * gq + 1] << 16);
+                                pk.y = ((unsigned)acc[4 * gq + 2] & 0xFFFFu) | ((unsigned)acc[4 * gq + 3] << 16);
+                                *(uint2 *)(dst + 8 * gq) = pk;
+                            }
                         }
                     }
                 }
@@ -909,11 +918,13 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
     __syncthreads();
     if (!active) return;
     // ---- orb.cpp computeOrbDescriptors: lane = 4 consecutive bit tests, vertical pass at the samples
-    const unsigned short *hs = (const unsigned short *)hb;
+    const uint8_t *hbytes = (const uint8_t *)hb;
     const float2 pt = kp_pt[g];
     const float sc = 1.f / L.scale;
     const int cx = __float2int_rn(pt.x * sc), cy = __float2int_rn(pt.y * sc);
     const int dxo = cx - x0 + 19, dyo = cy - y0 + KP_R - 3;       // (cx,cy) == (x0,y0) in practice
+    typedef unsigned short v2u16_t __attribute__((ext_vector_type(2)));
+    const v2u16_t T01 = {18, 34}, T23 = {49, 55}, T45 = {49, 34}, T6 = {18, 0};
     unsigned nib = 0;
 #pragma unroll
     for (int bit = 0; bit < 4; ++bit) {
@@ -925,10 +936,21 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
         const int ixs[2] = {__float2int_rn(fx0), __float2int_rn(fx1)}, iys[2] = {__float2int_rn(fy0), __float2int_rn(fy1)};
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const unsigned short *col = hs + (iys[e] + dyo) * (KP_H_DW * 2) + ixs[e] + dxo;
-            unsigned s = 18u * col[0] + 34u * col[KP_H_DW * 2] + 49u * col[2 * KP_H_DW * 2] + 55u * col[3 * KP_H_DW * 2] +
-                         49u * col[4 * KP_H_DW * 2] + 34u * col[5 * KP_H_DW * 2] + 18u * col[6 * KP_H_DW * 2];
-            t01[e] = (int)min((s + 32768u) >> 16, 255u);              // FixedPtCastEx<int, uchar> saturates (taps sum to 257)
+            // the 7 vertical taps = rows iy + dyo .. + 6 of column ix + dxo: 14 contiguous bytes at an even offset; read the
+            // three aligned 8-byte words that cover them, shift to the first tap, four v_dot2_u32_u16 against the tap pairs
+            const int addr = (ixs[e] + dxo) * (KP_HSTRIDE * 2) + (iys[e] + dyo) * 2;
+            const uint2 *wp = (const uint2 *)(hbytes + (addr & ~7));
+            const uint2 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+            const bool d1 = (addr & 4) != 0;                                   // first tap in the upper dword of w0
+            const unsigned sh = addr & 2;                                      // ... at its upper half
+            const unsigned a0 = d1 ? w0.y : w0.x, a1 = d1 ? w1.x : w0.y, a2 = d1 ? w1.y : w1.x, a3 = d1 ? w2.x : w1.y, a4 = d1 ? w2.y : w2.x;
+            const unsigned q0 = __builtin_amdgcn_alignbyte(a1, a0, sh), q1 = __builtin_amdgcn_alignbyte(a2, a1, sh),
+                           q2 = __builtin_amdgcn_alignbyte(a3, a2, sh), q3 = __builtin_amdgcn_alignbyte(a4, a3, sh);
+            unsigned s = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, q0), T01, 32768u, false);
+            s = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, q1), T23, s, false);
+            s = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, q2), T45, s, false);
+            s = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, q3), T6, s, false);
+            t01[e] = (int)min(s >> 16, 255u);                          // FixedPtCastEx<int, uchar> saturates (taps sum to 257)
         }
         nib |= (unsigned)(t01[0] < t01[1]) << bit;
     }
