@@ -19,9 +19,7 @@
 #define TW 64
 #define TH 64
 
-__constant__ signed char c_pattern[256 * 4] = {
-#include "brief_pattern.inc"
-};
+__device__ float4 c_pattern_f[256];         // rBRIEF pattern (brief_pattern.inc) as f32 (x0, y0, x1, y1), uploaded at handle creation
 __constant__ signed char c_disc[768 * 2];   // (u,v) offsets of the radius-15 disc
 __constant__ int c_ndisc;
 __constant__ signed char c_circ[16 * 2] = {0,3, 1,3, 2,2, 3,1, 3,0, 3,-1, 2,-2, 1,-3, 0,-3, -1,-3, -2,-2, -3,-1, -3,0, -3,1, -2,2, -1,3};
@@ -49,6 +47,14 @@ void rpe_orb_upload_disc(const signed char *disc, int n)
         wt[(v + 15) * 8 + j].y |= (unsigned)(u + 16) << (8 * b);
     }
     hipMemcpyToSymbol(HIP_SYMBOL(c_discw), wt, sizeof(wt));
+    {
+        static const signed char pat[256 * 4] = {
+#include "brief_pattern.inc"
+        };
+        std::vector<float> pf(1024);
+        for (int i = 0; i < 1024; ++i) pf[i] = (float)pat[i];
+        hipMemcpyToSymbol(HIP_SYMBOL(c_pattern_f), pf.data(), sizeof(float) * 1024);
+    }
     // banded tap matrix of the 7x7 Gaussian's horizontal pass, in MFMA B-operand order
     static const signed char tap[7] = {18, 34, 49, 55, 49, 34, 18};
     std::vector<signed char> tb((size_t)4 * 2 * 2 * 64 * 16, 0);
@@ -242,11 +248,13 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
                                                         int *__restrict__ tile_cnt, unsigned *__restrict__ hist, RpeDeviceLayout lay,
                                                         const RpeTile *__restrict__ tiles, int ntiles)
 {
-    __shared__ unsigned s_in[72 * 18];              // pixels  y0-4 .. y0+67, x0-4 .. x0+67
+    // 19.5 KB of LDS per workgroup = 8 workgroups (32 waves) per CU: the pixel tile is dead after phase 2, so the keypoint
+    // list and the histogram of phase 3 live in its place (4096 + 1024 <= 5184 bytes); at 24.5 KB only 6 workgroups fit
+    __shared__ __attribute__((aligned(16))) unsigned s_in[72 * 18];              // pixels  y0-4 .. y0+67, x0-4 .. x0+67
     __shared__ __attribute__((aligned(16))) unsigned s_sc[FS_ROWS * 18];   // scores  y0-1 .. y0+64, x0-4 .. x0+67
-    __shared__ __attribute__((aligned(16))) unsigned s_out[RPE_FAST_TILE_CAP];   // the tile's keypoint list
+    unsigned *s_out = s_in;                                               // phase 3: the tile's keypoint list [1024]
+    unsigned *s_hist = s_in + RPE_FAST_TILE_CAP;                          // phase 3: score histogram [256]
     __shared__ unsigned short s_cand[FS_ROWS * 72];
-    __shared__ unsigned s_hist[256];
     __shared__ int s_ncand, s_nout;
     const int tid = threadIdx.x, lane = tid & 63;
     const int ti = xcd_tile(blockIdx.x, ntiles);
@@ -266,7 +274,6 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
     }
     const uint8_t *src = pyr + ibase;
     if (tid == 0) { s_ncand = 0; s_nout = 0; }
-    s_hist[tid] = 0;
     {   // all tile loads in flight before the first LDS store.  lane -> fixed dword column (tid % 18) and rows
         // tid / 18 + 14 q: one column clamp and one division per tile instead of one per load
         const int lc = tid % 18, lr = tid / 18;
@@ -391,7 +398,10 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
     }
     __syncthreads();
     // ---- phase 3: NMS + border filter + histogram over the candidate list (only pixels that went through
-    // phase 2 can hold a score); survivors are appended to the tile's list, one LDS atomic per wave and round
+    // phase 2 can hold a score); survivors are appended to the tile's list, one LDS atomic per wave and round.
+    // The pixel tile is dead now (the barrier above ended phase 2): its LDS holds the list and the histogram.
+    s_hist[tid] = 0;
+    __syncthreads();
     const uint8_t *sc = (const uint8_t *)s_sc;
     for (int i0 = 0; i0 < ncand; i0 += 256) {                  // block-uniform trip count: the ballot sees whole waves
         const int i = i0 + tid;
@@ -928,24 +938,23 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
     unsigned nib = 0;
 #pragma unroll
     for (int bit = 0; bit < 4; ++bit) {
-        const signed char *pp = c_pattern + 4 * (lane * 4 + bit);
-        float p0 = (float)pp[0], p1 = (float)pp[1], p2 = (float)pp[2], p3 = (float)pp[3];
+        const float4 pf = c_pattern_f[lane * 4 + bit];
+        const float p0 = pf.x, p1 = pf.y, p2 = pf.z, p3 = pf.w;
         float fx0 = p0 * a - p1 * b, fy0 = p0 * b + p1 * a;
         float fx1 = p2 * a - p3 * b, fy1 = p2 * b + p3 * a;
         int t01[2];
         const int ixs[2] = {__float2int_rn(fx0), __float2int_rn(fx1)}, iys[2] = {__float2int_rn(fy0), __float2int_rn(fy1)};
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            // the 7 vertical taps = rows iy + dyo .. + 6 of column ix + dxo: 14 contiguous bytes at an even offset; read the
-            // three aligned 8-byte words that cover them, shift to the first tap, four v_dot2_u32_u16 against the tap pairs
+            // the 7 vertical taps = rows iy + dyo .. + 6 of column ix + dxo: 14 contiguous bytes at an even offset: the four
+            // dwords from the one holding the first tap cover them (2 + 14 = 16); shift by the half-word phase, four
+            // v_dot2_u32_u16 against the tap pairs (the 8th half-word meets a zero tap)
             const int addr = (ixs[e] + dxo) * (KP_HSTRIDE * 2) + (iys[e] + dyo) * 2;
-            const uint2 *wp = (const uint2 *)(hbytes + (addr & ~7));
-            const uint2 w0 = wp[0], w1 = wp[1], w2 = wp[2];
-            const bool d1 = (addr & 4) != 0;                                   // first tap in the upper dword of w0
-            const unsigned sh = addr & 2;                                      // ... at its upper half
-            const unsigned a0 = d1 ? w0.y : w0.x, a1 = d1 ? w1.x : w0.y, a2 = d1 ? w1.y : w1.x, a3 = d1 ? w2.x : w1.y, a4 = d1 ? w2.y : w2.x;
+            const unsigned *wp = (const unsigned *)(hbytes + (addr & ~3));
+            const unsigned a0 = wp[0], a1 = wp[1], a2 = wp[2], a3 = wp[3];
+            const unsigned sh = addr & 2;
             const unsigned q0 = __builtin_amdgcn_alignbyte(a1, a0, sh), q1 = __builtin_amdgcn_alignbyte(a2, a1, sh),
-                           q2 = __builtin_amdgcn_alignbyte(a3, a2, sh), q3 = __builtin_amdgcn_alignbyte(a4, a3, sh);
+                           q2 = __builtin_amdgcn_alignbyte(a3, a2, sh), q3 = __builtin_amdgcn_alignbyte(0u, a3, sh);
             unsigned s = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, q0), T01, 32768u, false);
             s = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, q1), T23, s, false);
             s = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, q2), T45, s, false);
