@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
     const RpePyrTile pt = ptiles[ti];
     const int x0 = pt.x0, y0 = pt.y0, a0 = pt.a0, sy0 = pt.sy0;
     uint8_t *base = pyr + (long long)blockIdx.y * lay.stride;
-    const uint8_t *src = base + S.off;
+    const uint8_t *src = rpe_level_base(pyr, lay, blockIdx.y, l - 1);
     // packed (offset | weight << 16) per destination column / row; the device table pads the x run to a multiple of 128
     // and the y run to a multiple of 64 entries (last entry replicated) and aligns both to 16 B, so a lane fetches its
     // 4 columns with one 16-B load and its 8 rows with two, without clamps
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
         const uint8_t *colp = src + min(a0 + 16 * c, S.pitch - 16);      // pitch is a multiple of 16; clamped columns are never read
         uint4 stage[NLD];
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) stage[q] = *(const uint4 *)(colp + (unsigned)(min(sy0 + r + 16 * q, S.h - 1) * S.pitch));
+        for (int q = 0; q < NLD; ++q) stage[q] = *(const uint4 *)(colp + __umul24((unsigned)min(sy0 + r + 16 * q, S.h - 1), (unsigned)S.pitch));   // v_mul_lo_u32 is quarter rate
         if (c < NQ) {
 #pragma unroll
             for (int q = 0; q < NLD; ++q) { const int rr = r + 16 * q; if (rr < PYR_ROWS) ((uint4 *)s_src)[rr * NQ + c] = stage[q]; }
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
     if (x4 >= D.pitch) return;
     // horizontal pass of one source row for this lane's 4 columns
     auto hrow = [&](int srow, unsigned (&hh)[4]) {
-        const unsigned *rw = s_src + (srow - sy0) * PYR_DW + dw0;
+        const unsigned *rw = s_src + __mul24(srow - sy0, PYR_DW) + dw0;
         const unsigned d0 = rw[0], d1 = rw[1], d2 = rw[2];
         const unsigned w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
         const unsigned p0 = __builtin_amdgcn_perm(w1, w0, sel0), p1 = __builtin_amdgcn_perm(w1, w0, sel1);
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
     unsigned hc[4] = {0, 0, 0, 0};
     int cached = -1;
     const unsigned colmask = x4 + 3 < D.w ? 0xFFFFFFFFu : (x4 >= D.w ? 0u : (0xFFFFFFFFu >> (8 * (x4 + 4 - D.w))));   // bytes past D.w stay 0
-    uint8_t *dstp = base + D.off + (unsigned)((y0 + ty8 * 8) * D.pitch) + x4;
+    uint8_t *dstp = base + D.off + __umul24((unsigned)(y0 + ty8 * 8), (unsigned)D.pitch) + x4;
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
         const int y = y0 + ty8 * 8 + rr;
@@ -200,9 +200,12 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
         }
         cached = bot;
         const unsigned b1u = (unsigned)b1[rr], b0u = 256u - b1u;
-        unsigned out = 0;
+        // the four results are byte 2 of four 24-bit sums: two v_perm_b32 pick them (a shift/or chain makes the compiler
+        // turn the last column's 24-bit multiplies into quarter-rate v_mul_lo_u32 / v_mad_u64_u32)
+        unsigned sm[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out |= ((__umul24(b0u, ht[j]) + __umul24(b1u, hc[j]) + 32768u) >> 16) << (8 * j);
+        for (int j = 0; j < 4; ++j) sm[j] = __umul24(b0u, ht[j]) + __umul24(b1u, hc[j]) + 32768u;
+        const unsigned out = __builtin_amdgcn_perm(sm[1], sm[0], 0x0c0c0602u) | __builtin_amdgcn_perm(sm[3], sm[2], 0x06020c0cu);
         *(unsigned *)dstp = out & colmask;
         dstp += D.pitch;
     }
@@ -263,7 +266,6 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
     const RpeLevel &L = lay.lv[t.level];
     const int w = L.w, hgt = L.h, pitch = L.pitch, thr = lay.fast_thr;
     const int x0 = t.tx, y0 = t.ty;
-    const long long ibase = (long long)blockIdx.y * lay.stride + L.off;
     const long long tslot = (long long)blockIdx.y * ntiles + ti;
     // tiles that cannot contain a keypoint after the border filter (the host table lists none): empty list
     const bool live = w > 2 * RPE_EDGE && hgt > 2 * RPE_EDGE && x0 < w - RPE_EDGE && x0 + 64 > RPE_EDGE &&
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
         if (tid == 0) tile_cnt[tslot] = 0;
         return;
     }
-    const uint8_t *src = pyr + ibase;
+    const uint8_t *src = rpe_level_base(pyr, lay, blockIdx.y, t.level);
     if (tid == 0) { s_ncand = 0; s_nout = 0; }
     {   // all tile loads in flight before the first LDS store.  lane -> fixed dword column (tid % 18) and rows
         // tid / 18 + 14 q: one column clamp and one division per tile instead of one per load
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
         for (int q = 0; q < 6; ++q) {
             const int r = min(lr + 14 * q, 71);
             const int y = min(max(y0 - 4 + r, 0), hgt - 1);
-            stage[q] = *(const unsigned *)(src + (long long)y * pitch + lx);
+            stage[q] = *(const unsigned *)(src + (__umul24((unsigned)y, (unsigned)pitch) + (unsigned)lx));
         }
 #pragma unroll
         for (int q = 0; q < 6; ++q) { const int r = lr + 14 * q; if (tid < 252 && r < 72) s_in[r * 18 + lc] = stage[q]; }
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(256) void harris_kernel(const uint8_t *__restrict__
     // instead of 81 dependent byte loads -- the kernel was bound by the number of memory instructions, not by bytes
     // (0.05 G vector instructions in 0.5 ms).  Reads stay inside the row: x0 >= 31 and x0 + 7 < w - 24 <= pitch.
     const int sh = x0 & 3;
-    const uint8_t *p0 = pyr + (long long)img * lay.stride + L.off + (long long)(y0 - 4) * pitch + ((x0 - 4) & ~3);
+    const uint8_t *p0 = rpe_level_base(pyr, lay, img, l) + (long long)(y0 - 4) * pitch + ((x0 - 4) & ~3);
     unsigned w[9][3];
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
@@ -830,7 +832,7 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
     const int xal = (x0 - KP_R) & ~3, off0 = (x0 - KP_R) - xal;     // off0 in 0..3
     unsigned *raw = s_raw[wv], *hb = s_hb[wv];
     if (active) {
-        const uint8_t *src = pyr + (long long)img * lay.stride + L.off + (long long)(y0 - KP_R) * pitch + xal;
+        const uint8_t *src = rpe_level_base(pyr, lay, img, l) + (long long)(y0 - KP_R) * pitch + xal;
         // lane -> fixed dword column (lane % 12) and rows lane / 12 + 5 q (60 lanes x 9 loads = 45 x 12 dwords)
         const int lc = lane % KP_RAW_DW, lr = lane / KP_RAW_DW;
         unsigned stage[9];

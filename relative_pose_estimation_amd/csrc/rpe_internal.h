@@ -37,7 +37,20 @@ struct RpeDeviceLayout {       // passed by value to kernels
     int cand_total;            // candidates capacity per image (sum ccap)
     int kcap;                  // keypoints capacity per image
     int fast_thr;
+    // level 0 read IN PLACE from the caller's image batches when its pitch equals the image width (width % 16 == 0):
+    // slot i < in_na is image i of in_a, the others image i - in_na of in_b (a consecutive-frame stream passes one
+    // buffer and in_na = frames).  in_a == nullptr: level 0 was copied into the pyramid buffer like the other levels.
+    const uint8_t *in_a, *in_b;
+    int in_na, in_img;         // in_img = width * height
 };
+
+// base address of level l of image slot img (see in_a above)
+__device__ __forceinline__ const uint8_t *rpe_level_base(const uint8_t *pyr, const RpeDeviceLayout &lay, int img, int l)
+{
+    if (l == 0 && lay.in_a)
+        return img < lay.in_na ? lay.in_a + (long long)img * lay.in_img : lay.in_b + (long long)(img - lay.in_na) * lay.in_img;
+    return pyr + (long long)img * lay.stride + lay.lv[l].off;
+}
 
 struct RpeTile { short level, tx, ty, pad; };
 // 128x64 destination tile of the resize kernel: destination origin and origin of its source window in the level below
@@ -70,7 +83,7 @@ struct rpe_handle {
     hipStream_t copy_stream = nullptr;          // uploads of a chunked host batch (rpe_estimate_batch), created on first use
     hipEvent_t ev_up[8] = {};                   // 'chunk c is resident' events
     bool last_chunked = false;                  // the last host batch ran in chunks: per-pair debug arrays hold its last chunk only
-    RpeDeviceLayout lay;
+    RpeDeviceLayout lay{};
     int n_img_cap = 0;              // 2*max_batch
     // tile tables
     RpeTile *d_tiles_full = nullptr;  int n_tiles_full = 0;   // 64x16 tiles covering every level
@@ -96,6 +109,7 @@ struct rpe_handle {
     int *d_kp_count = nullptr;        // [img]
     unsigned *d_ovf = nullptr;        // [img] RPE_OVF_* capacity flags of the last extraction
     int last_pairs = 0, last_img2_base = 0;   // image slots of the last batch's pairs: (p, last_img2_base + p)
+    int level0_slots = 0;             // image slots of the last ORB run (debug fetch of an in-place level 0)
     uint8_t *d_desc = nullptr;        // [img][kcap][32]
     // matching
     int *d_m_q = nullptr, *d_m_t = nullptr, *d_m_d = nullptr, *d_m_n = nullptr;

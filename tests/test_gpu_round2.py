@@ -306,6 +306,30 @@ def test_native_pose_gather_world1(capi, K_vga):
     e.close()
 
 
+def test_level0_in_place_and_copied_agree(capi, K_vga):
+    """Level 0 of the ORB pyramid is read in place from the caller's device batches when the width is a multiple of 16
+    and the batches are 16-byte aligned; a batch at an unaligned device address takes the copy into the pyramid buffer.
+    Both routes give the same bits, and the pyramid debug fetch returns level 0 either way."""
+    import ctypes
+    from relative_pose_estimation_amd import synthetic
+    i1, i2, _, _ = synthetic.make_batch(2, K_vga, cfg=2)
+    e = capi.Engine(640, 480, max_batch=2, nfeatures=1000, max_matches=500)
+    da, db = e.upload(i1), e.upload(i2)
+    e.enqueue_batch_device(da, db, 2, K_vga)
+    ref = e.fetch_results(2)
+    pyr = e.orb_debug_fetch(2, 0)                                   # slot 2 = first image of the second batch
+    assert np.array_equal(pyr[:640 * 480].reshape(480, 640), i2[0])
+    pad1 = np.concatenate([np.zeros(4, np.uint8), i1.reshape(-1)]); pad2 = np.concatenate([np.zeros(4, np.uint8), i2.reshape(-1)])
+    ua, ub = e.upload(pad1), e.upload(pad2)
+    e.enqueue_batch_device(ctypes.c_void_p(ua.value + 4), ctypes.c_void_p(ub.value + 4), 2, K_vga)
+    got = e.fetch_results(2)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    assert (ref[4] == 0).all()
+    assert np.array_equal(e.orb_debug_fetch(2, 0), pyr)
+    e.close()
+
+
 # ------------------------------------------------------------------ roofline calibration entry points
 def test_calibration_entry_points(capi):
     """rpe_calibrate_valu / rpe_calibrate_hbm run and give physically possible rates: integer and f64 instructions issue
