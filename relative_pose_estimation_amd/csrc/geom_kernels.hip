@@ -4,7 +4,7 @@
 // (reference src/core/pose_estimator.py:522-527) and cv2.recoverPose(E, pts1, pts2, K)
 // (:533).  Sequential OpenCV semantics (calib3d/ptsetreg.cpp RANSACPointSetRegistrator::run:
 // fixed RNG stream, "strictly more inliers wins", adaptive niters) are reproduced on a
-// parallel machine by evaluating a chunk of iterations at a time (64, 64, 128, 256, 512) and replaying
+// parallel machine by evaluating a chunk of iterations at a time (32, 96, 384, 512) and replaying
 // the update rule over the per-model inlier counts:
 //   ransac_prepare : normalise points with K (f64), reset per-pair state
 //   ransac_poly    : one lane = one minimal sample: null space, 10x20 elimination in lane-interleaved
@@ -21,6 +21,8 @@
 // All f64 arithmetic uses the oracle's operation order (compiled with -ffp-contract=off).
 #include "rpe_internal.h"
 #include <float.h>
+#include <stdlib.h>
+#include <algorithm>
 
 // ------------------------------------------------ polynomial bookkeeping
 // lin: x y z 1 ; quad: x2 y2 z2 xy xz yz x y z 1 ;
@@ -108,21 +110,25 @@ __device__ __forceinline__ double root_bound_s(const double (&p)[11])
     return R;
 }
 
-// generic path (degree < 10 after leading-coefficient trimming: rare): dynamic indexing
-__device__ static int poly_real_roots_generic(const double *c, int n, double *roots)
+// generic path (leading coefficient trimmed to degree < 10: rare): one lane walks the whole chain serially with dynamic
+// indexing.  Its arrays live in workspace the CALLER
+// provides (LDS in ransac_roots_kernel): as private arrays they are a scratch segment, and a kernel with one is
+// dispatched with fewer resident waves.  Level k's polynomial is c differentiated n - k times, rebuilt from c on every
+// level by the same multiplications in the same order as the oracle's derivative table (identical values), so the
+// workspace is two rows instead of the 11 x 11 table.
+#define GEN_WS_DOUBLES (4 * 11)          // p[11], dp[11], rts[2][11]
+__device__ static int poly_real_roots_generic(const double *c, int n, double *roots, double *ws)
 {
-    double d[11][11];
-    double rts[2][11];
+    double *p = ws, *dp = ws + 11, *rts = ws + 22;          // rts[which * 11 + i]
     int nr_prev = 0, cur = 0;
-    for (int i = 0; i <= n; ++i) d[n][i] = c[i];
-    for (int k = n; k >= 2; --k)
-        for (int i = 0; i < k; ++i) d[k - 1][i] = d[k][i + 1] * (double)(i + 1);
-    rts[0][0] = -d[1][0] / d[1][1];
-    nr_prev = 1; cur = 0;
-    for (int k = 2; k <= n; ++k) {
-        const double *p = d[k];
-        const double *crit = rts[cur];
-        double *out = rts[cur ^ 1];
+    for (int k = 1; k <= n; ++k) {
+        for (int i = 0; i <= n; ++i) p[i] = c[i];
+        for (int kk = n; kk > k; --kk)
+            for (int i = 0; i < kk; ++i) p[i] = p[i + 1] * (double)(i + 1);
+        if (k == 1) { rts[0] = -p[0] / p[1]; nr_prev = 1; cur = 0; continue; }
+        for (int i = 0; i < k; ++i) dp[i] = p[i + 1] * (double)(i + 1);
+        const double *crit = rts + cur * 11;
+        double *out = rts + (cur ^ 1) * 11;
         int nout = 0;
         double R = root_bound(p, k);
         for (int iv = 0; iv <= nr_prev; ++iv) {
@@ -133,11 +139,11 @@ __device__ static int poly_real_roots_generic(const double *c, int n, double *ro
             if (!(a < b)) continue;
             int sa = horner(p, k, a) > 0., sb = horner(p, k, b) > 0.;
             if (sa == sb) continue;
-            out[nout++] = refine_root(p, d[k - 1], k, a, b, sa);
+            out[nout++] = refine_root(p, dp, k, a, b, sa);
         }
         nr_prev = nout; cur ^= 1;
     }
-    for (int i = 0; i < nr_prev; ++i) roots[i] = rts[cur][i];
+    for (int i = 0; i < nr_prev; ++i) roots[i] = rts[cur * 11 + i];
     return nr_prev;
 }
 
@@ -390,14 +396,18 @@ __global__ __launch_bounds__(POLY_LANES) void ransac_poly_kernel(const double2 *
     nmodels[slot] = ok ? -1 : 0;          // -1: record valid, roots pending
 }
 
-// B: roots + back-substitution, RG = 16 lanes per minimal sample.  The real roots of the degree-k
+// B: roots + back-substitution, RG = 8 lanes per minimal sample.  The real roots of the degree-k
 // derivative split the line into <= k+1 intervals with at most one root of the degree-(k+1)
 // derivative each, and those intervals are independent: lane j of a group brackets and refines
 // interval j, the roots are compacted in interval order (ballot + n-th set bit + shuffle), so every
 // lane performs exactly the arithmetic the sequential oracle performs for that interval and the
-// root list comes out in the same order.  16x more waves than lane-per-sample and a 10x shorter
-// dependent chain per wave: the stage is f64-throughput bound instead of single-wave-latency bound.
-#define RG 16
+// root list comes out in the same order.  The kernel is bound by vector-instruction issue (r02 PMC: 0.2 G
+// instructions in 0.43 ms for the first 64-iteration chunk, 76 % of the measured issue roof), and a wave costs what
+// its slowest interval costs whatever the number of busy lanes: with 16 lanes per sample 70 % of the lanes idled (the
+// derivative chain of these polynomials rarely has more than 4 real roots on a level); 8 lanes per sample halve the
+// waves.  A level with more than 8 intervals (>= 8 real roots below it: levels 9 and 10 only) takes two rounds.
+#define RG 8
+#define RPE_RANSAC_FIRST_CHUNK 32   // iterations of the first launch group (schedule: rpe_launch_ransac)
 __device__ __forceinline__ int nth_set_bit(unsigned m, int k)
 {
     for (int t = 0; t < k; ++t) m &= m - 1;
@@ -429,18 +439,65 @@ __device__ __forceinline__ int roots_level_grp(const double (&c)[11], double &cr
         const int sa = horner_s<K>(p, a) > 0., sb = horner_s<K>(p, b) > 0.;
         if (sa != sb) { root = refine_root_s<K>(p, dp, a, b, sa); has = true; }
     }
-    const unsigned m = (unsigned)(__ballot(has) >> gbase) & 0xFFFFu;
+    const unsigned m = (unsigned)(__ballot(has) >> gbase) & ((1u << RG) - 1u);
     crit = __shfl(root, gbase + nth_set_bit(m, j));
     return __popc(m);
 }
 
-__global__ __launch_bounds__(256) void ransac_roots_kernel(const RpeRansacState *__restrict__ st, const double *__restrict__ hyp,
-                                                            double *__restrict__ models, int *__restrict__ nmodels, int n_pairs,
-                                                            int waves_per_pair)
+// Levels 9 and 10 can have 9 / 10 intervals (8 / 9 real roots below): lane j then also takes interval 8 + j in a second
+// round (lanes 0 and 1 only) and keeps root #(8 + j) in crit1.  Same arithmetic per interval, same root order.
+template <int K>
+__device__ __forceinline__ int roots_level_grp2(const double (&c)[11], double &crit0, double &crit1, int nr_prev, int j, int gbase)
 {
+    double p[11], dp[11];
+#pragma unroll
+    for (int i = 0; i <= 10; ++i) p[i] = c[i];
+#pragma unroll
+    for (int kk = 10; kk > K; --kk)
+#pragma unroll
+        for (int i = 0; i < kk; ++i) p[i] = p[i + 1] * (double)(i + 1);
+#pragma unroll
+    for (int i = 0; i < K; ++i) dp[i] = p[i + 1] * (double)(i + 1);
+    const double R = root_bound_s<K>(p);
+    // crit[iv - 1] and crit[iv] of this lane's interval in each round (nr_prev >= RG here)
+    const double below0 = __shfl_up(crit0, 1);                    // crit[j - 1]
+    const double c7 = __shfl(crit0, gbase + RG - 1), c8 = __shfl(crit1, gbase);
+    double root[2] = {0., 0.};
+    bool has[2] = {false, false};
+#pragma unroll 1
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        const int iv = rnd * RG + j;
+        double a = rnd == 0 ? (j == 0 ? -R : below0) : (j == 0 ? c7 : c8);
+        double b = (iv == nr_prev) ? R : (rnd == 0 ? crit0 : crit1);
+        if (a < -R) a = -R;
+        if (b > R) b = R;
+        bool h = false;
+        double r = 0.;
+        if (iv <= nr_prev && a < b) {
+            const int sa = horner_s<K>(p, a) > 0., sb = horner_s<K>(p, b) > 0.;
+            if (sa != sb) { r = refine_root_s<K>(p, dp, a, b, sa); h = true; }
+        }
+        if (rnd == 0) { root[0] = r; has[0] = h; } else { root[1] = r; has[1] = h; }
+    }
+    const unsigned mA = (unsigned)(__ballot(has[0]) >> gbase) & ((1u << RG) - 1u);
+    const unsigned mB = (unsigned)(__ballot(has[1]) >> gbase) & ((1u << RG) - 1u);
+    const int nA = __popc(mA), nB = __popc(mB);
+    // root #r of this level: the r-th found in round 0, then those of round 1
+    const double a0 = __shfl(root[0], gbase + nth_set_bit(mA, j)), b0 = __shfl(root[1], gbase + nth_set_bit(mB, max(j - nA, 0)));
+    const double a1 = __shfl(root[0], gbase + nth_set_bit(mA, min(j + RG, 31))), b1 = __shfl(root[1], gbase + nth_set_bit(mB, max(j + RG - nA, 0)));
+    crit0 = j < nA ? a0 : b0;
+    crit1 = j + RG < nA ? a1 : b1;
+    return nA + nB;
+}
+
+#define ROOTS_WS (GEN_WS_DOUBLES + 11 + 10)      // generic-path workspace + coefficients + root list, per group
+__global__ __launch_bounds__(256, 4) void ransac_roots_kernel(const RpeRansacState *__restrict__ st, const double *__restrict__ hyp,
+                                                               double *__restrict__ models, int *__restrict__ nmodels, int n_pairs,
+                                                               int per_pair /* samples of a pair in this launch: the chunk */)
+{
+    __shared__ double s_gen[256 / RG][ROOTS_WS];
     const int tid = threadIdx.x, j = tid & (RG - 1), gbase = tid & 63 & ~(RG - 1);
     const long long sidx = (long long)blockIdx.x * (256 / RG) + (tid / RG);     // sample = (pair, wv, lane)
-    const int per_pair = waves_per_pair * 64;
     const int pair = (int)(sidx / per_pair), rem = (int)(sidx - (long long)pair * per_pair);
     const int wv = rem >> 6, lane = rem & 63;
     if (pair >= n_pairs) return;
@@ -453,9 +510,10 @@ __global__ __launch_bounds__(256) void ransac_roots_kernel(const RpeRansacState 
 #pragma unroll
     for (int i = 0; i < 11; ++i) c10[i] = rec[i * 64];
     const int n = (int)rec[86 * 64];
-    double z = 0.;
-    int nroots;
-    if (n == 10) {
+    double z = 0., z1 = 0.;            // roots #j and #(RG + j) of the current level
+    int nroots = 0;
+    const bool generic = (n != 10);
+    if (!generic) {
         {
             double p[11];
 #pragma unroll
@@ -467,6 +525,8 @@ __global__ __launch_bounds__(256) void ransac_roots_kernel(const RpeRansacState 
             z = -p[0] / p[1];
         }
         nroots = 1;
+        // a level has nroots + 1 intervals; levels 2..8 cannot exceed the 8 lanes (nroots <= K - 1 <= 7 below level K <= 8),
+        // levels 9 and 10 take a second round when they do
         nroots = roots_level_grp<2>(c10, z, nroots, j, gbase);
         nroots = roots_level_grp<3>(c10, z, nroots, j, gbase);
         nroots = roots_level_grp<4>(c10, z, nroots, j, gbase);
@@ -474,71 +534,85 @@ __global__ __launch_bounds__(256) void ransac_roots_kernel(const RpeRansacState 
         nroots = roots_level_grp<6>(c10, z, nroots, j, gbase);
         nroots = roots_level_grp<7>(c10, z, nroots, j, gbase);
         nroots = roots_level_grp<8>(c10, z, nroots, j, gbase);
-        nroots = roots_level_grp<9>(c10, z, nroots, j, gbase);
-        nroots = roots_level_grp<10>(c10, z, nroots, j, gbase);
-    } else {
-        // trimmed leading coefficient (rare): the group leader runs the generic chain serially
-        double rl[10];
-#pragma unroll
-        for (int t = 0; t < 10; ++t) rl[t] = 0.;
-        int nr = 0;
-        if (j == 0) nr = poly_real_roots_generic(c10, n, rl);
-        nroots = __shfl(nr, gbase);
-#pragma unroll
-        for (int t = 0; t < 10; ++t) { const double v = __shfl(rl[t], gbase); if (j == t) z = v; }
+        if (nroots + 1 > RG) nroots = roots_level_grp2<9>(c10, z, z1, nroots, j, gbase);       // group-uniform
+        else nroots = roots_level_grp<9>(c10, z, nroots, j, gbase);
+        if (nroots + 1 > RG) nroots = roots_level_grp2<10>(c10, z, z1, nroots, j, gbase);
+        else nroots = roots_level_grp<10>(c10, z, nroots, j, gbase);
     }
-    // back-substitution: lane j <- root #j (five_point_roots' loop body), models compacted in root order
-    bool okm = false;
-    double Ev[9];
-    if (j < nroots) {
-        double bz[3][3];
+    double *ws = s_gen[tid / RG];
+    if (generic) {
+        // the group leader runs the whole chain serially in its LDS workspace (groups are wave-local: the leader's LDS
+        // writes are visible to its neighbours after the wave barrier)
+        int nr = 0;
+        if (j == 0) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const double x3 = rec[(11 + i * 4 + 3) * 64], x2 = rec[(11 + i * 4 + 2) * 64], x1 = rec[(11 + i * 4 + 1) * 64], x0 = rec[(11 + i * 4) * 64];
-            const double y3 = rec[(23 + i * 4 + 3) * 64], y2 = rec[(23 + i * 4 + 2) * 64], y1 = rec[(23 + i * 4 + 1) * 64], y0 = rec[(23 + i * 4) * 64];
-            const double w4 = rec[(35 + i * 5 + 4) * 64], w3 = rec[(35 + i * 5 + 3) * 64], w2 = rec[(35 + i * 5 + 2) * 64],
-                         w1 = rec[(35 + i * 5 + 1) * 64], w0 = rec[(35 + i * 5) * 64];
-            bz[i][0] = ((x3 * z + x2) * z + x1) * z + x0;
-            bz[i][1] = ((y3 * z + y2) * z + y1) * z + y0;
-            bz[i][2] = (((w4 * z + w3) * z + w2) * z + w1) * z + w0;
+            for (int t = 0; t < 11; ++t) ws[GEN_WS_DOUBLES + t] = c10[t];
+            nr = poly_real_roots_generic(ws + GEN_WS_DOUBLES, n, ws + GEN_WS_DOUBLES + 11, ws);
         }
-        double bestn = -1., xv0 = 0., xv1 = 0., xv2 = 0.;
+        __builtin_amdgcn_wave_barrier();
+        nroots = __shfl(nr, gbase);
+    }
+    // back-substitution: lane j <- root #j (five_point_roots' loop body), models compacted in root order; more than RG
+    // roots (generic path only) take a second round
+    int nmod = 0;
+    for (int r0 = 0; r0 < nroots; r0 += RG) {                          // group-uniform trip count (1, rarely 2)
+        const int ri = r0 + j;
+        __asm__ volatile("" ::: "memory");     // keep the ~75 record loads inside the round: hoisted out of the loop they spill
+        if (generic) { if (ri < nroots) z = ws[GEN_WS_DOUBLES + 11 + ri]; }
+        else if (r0) z = z1;
+        bool okm = false;
+        double Ev[9];
+        if (ri < nroots) {
+            double bz[3][3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int r0 = i, r1 = (i + 1) % 3;
-            const double cx = bz[r0][1] * bz[r1][2] - bz[r0][2] * bz[r1][1];
-            const double cy = bz[r0][2] * bz[r1][0] - bz[r0][0] * bz[r1][2];
-            const double cz = bz[r0][0] * bz[r1][1] - bz[r0][1] * bz[r1][0];
-            const double nn = cx * cx + cy * cy + cz * cz;
-            if (nn > bestn) { bestn = nn; xv0 = cx; xv1 = cy; xv2 = cz; }
-        }
-        if (bestn > 0.) {
-            const double inv = 1. / sqrt(bestn);
-            const double w = xv2 * inv;
-            if (!(fabs(w) < 1e-10)) {
-                const double x = xv0 / xv2, y = xv1 / xv2;
-                double nrm = 0.;
+            for (int i = 0; i < 3; ++i) {
+                const double x3 = rec[(11 + i * 4 + 3) * 64], x2 = rec[(11 + i * 4 + 2) * 64], x1 = rec[(11 + i * 4 + 1) * 64], x0 = rec[(11 + i * 4) * 64];
+                const double y3 = rec[(23 + i * 4 + 3) * 64], y2 = rec[(23 + i * 4 + 2) * 64], y1 = rec[(23 + i * 4 + 1) * 64], y0 = rec[(23 + i * 4) * 64];
+                const double w4 = rec[(35 + i * 5 + 4) * 64], w3 = rec[(35 + i * 5 + 3) * 64], w2 = rec[(35 + i * 5 + 2) * 64],
+                             w1 = rec[(35 + i * 5 + 1) * 64], w0 = rec[(35 + i * 5) * 64];
+                bz[i][0] = ((x3 * z + x2) * z + x1) * z + x0;
+                bz[i][1] = ((y3 * z + y2) * z + y1) * z + y0;
+                bz[i][2] = (((w4 * z + w3) * z + w2) * z + w1) * z + w0;
+            }
+            double bestn = -1., xv0 = 0., xv1 = 0., xv2 = 0.;
 #pragma unroll
-                for (int e = 0; e < 9; ++e) {
-                    Ev[e] = ((rec[(50 + e) * 64] * x + rec[(59 + e) * 64] * y) + rec[(68 + e) * 64] * z) + rec[(77 + e) * 64];
-                    nrm += Ev[e] * Ev[e];
-                }
-                nrm = sqrt(nrm);
-                if (nrm > 0.) {
-                    okm = true;
+            for (int i = 0; i < 3; ++i) {
+                const int q0 = i, q1 = (i + 1) % 3;
+                const double cx = bz[q0][1] * bz[q1][2] - bz[q0][2] * bz[q1][1];
+                const double cy = bz[q0][2] * bz[q1][0] - bz[q0][0] * bz[q1][2];
+                const double cz = bz[q0][0] * bz[q1][1] - bz[q0][1] * bz[q1][0];
+                const double nn = cx * cx + cy * cy + cz * cz;
+                if (nn > bestn) { bestn = nn; xv0 = cx; xv1 = cy; xv2 = cz; }
+            }
+            if (bestn > 0.) {
+                const double inv = 1. / sqrt(bestn);
+                const double w = xv2 * inv;
+                if (!(fabs(w) < 1e-10)) {
+                    const double x = xv0 / xv2, y = xv1 / xv2;
+                    double nrm = 0.;
 #pragma unroll
-                    for (int e = 0; e < 9; ++e) Ev[e] = Ev[e] / nrm;
+                    for (int e = 0; e < 9; ++e) {
+                        Ev[e] = ((rec[(50 + e) * 64] * x + rec[(59 + e) * 64] * y) + rec[(68 + e) * 64] * z) + rec[(77 + e) * 64];
+                        nrm += Ev[e] * Ev[e];
+                    }
+                    nrm = sqrt(nrm);
+                    if (nrm > 0.) {
+                        okm = true;
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) Ev[e] = Ev[e] / nrm;
+                    }
                 }
             }
         }
-    }
-    const unsigned m = (unsigned)(__ballot(okm) >> gbase) & 0xFFFFu;
-    if (okm) {
-        double *dst = models + (slot * RPE_MAX_MODELS + __popc(m & ((1u << j) - 1u))) * 9;
+        const unsigned m = (unsigned)(__ballot(okm) >> gbase) & ((1u << RG) - 1u);
+        if (okm) {
+            double *dst = models + (slot * RPE_MAX_MODELS + nmod + __popc(m & ((1u << j) - 1u))) * 9;
 #pragma unroll
-        for (int e = 0; e < 9; ++e) dst[e] = Ev[e];
+            for (int e = 0; e < 9; ++e) dst[e] = Ev[e];
+        }
+        nmod += __popc(m);
     }
-    if (j == 0) nmodels[slot] = __popc(m);
+    if (j == 0) nmodels[slot] = nmod;
 }
 
 // ------------------------------------------------------- Sampson inlier test
@@ -808,20 +882,36 @@ void rpe_launch_ransac(rpe_handle *h, int B, bool want_mask)
     double2 *n1 = h->d_n1, *n2 = h->d_n2;
     hipLaunchKernelGGL(ransac_prepare_kernel, dim3((mm + 255) / 256, B), dim3(256), 0, h->stream,
                        h->d_pts1, h->d_pts2, h->d_m_n, h->d_K, n1, n2, h->d_rstate, h->d_found, mm, it);
-    // chunk schedule 64, 64, 128, 256, 512, 512, ...: most pairs stop inside the first 64 iterations;
-    // launches are bound by single-wave latency, so long-running pairs get more waves per launch.
-    // (64, 512, 512 was measured in round 2: 2.05 -> 2.11 ms -- every wave of the poly kernel reserves 100 KB of
-    // LDS, so the 8 x 1024 mostly empty waves of a 512-chunk queue up one per CU.)
+    // chunk schedule 32, 96, 384, 512, 512, ... (cumulative 32, 128, 512, 1024).  A launch group costs
+    //   max(latency floor, work): the floor is one wave's dependent chain through poly -> roots -> score -> update
+    //   (~170-200 us whatever the number of pairs still running), the work is ~12.6 ns per (pair, iteration) that is
+    //   still below its pair's current niters (r02 trace: 414 us for 1024 pairs x 32 iterations).
+    // RANSACUpdateNumIters ends most pairs early (inlier ratio 0.72 -> 32 iterations, 0.64 -> 64), so the first group is
+    // small (its whole chunk is evaluated for every pair); after it the launches are floor-bound and every extra group
+    // costs a floor, so the chunks grow fast.  Measured on the 1024-pair bench batch (same box, interleaved):
+    //   64,64,128,256,512: 1.58 ms   32,32,64,128,256,512: 1.43   32,32,64,384,512: 1.29   32,96,384,512: 1.20
+    //   32,480,512: 1.23   64,448,512: 1.26   96,416,512: 1.40   (results identical: the replay in ransac_update_kernel
+    //   is exact for any chunking).
     const int use_lds = mm <= 2048;
     const size_t lds = use_lds ? sizeof(double2) * 2 * (size_t)mm : 0;
-    int done_iters = 0, chunk = 64, nlaunch = 0;
+    static_assert(RPE_RANSAC_FIRST_CHUNK % POLY_LANES == 0 && RPE_RANSAC_FIRST_CHUNK % SCORE_GROUP == 0 && (RPE_RANSAC_FIRST_CHUNK * RG) % 256 == 0, "chunk granularity");
+    // experiment hook: RPE_RANSAC_SCHEDULE="32,96,384,512" replaces the chunk schedule (multiples of 32, <= 512; the last
+    // entry repeats)
+    static std::vector<int> env_sched = [] {
+        std::vector<int> v;
+        if (const char *e = getenv("RPE_RANSAC_SCHEDULE")) {
+            for (const char *q = e; *q;) { const int c = atoi(q); if (c >= 32 && c <= RPE_RANSAC_MAXCHUNK && c % 32 == 0) v.push_back(c); while (*q && *q != ',') ++q; if (*q) ++q; }
+        }
+        return v;
+    }();
+    static const int kSchedule[] = {RPE_RANSAC_FIRST_CHUNK, 96, 384, RPE_RANSAC_MAXCHUNK};
+    int done_iters = 0, chunk = env_sched.empty() ? kSchedule[0] : env_sched[0], nlaunch = 0;
     while (done_iters < it) {
-        const int wpp = chunk / 64;
-        hipLaunchKernelGGL(ransac_poly_kernel, dim3(B, wpp * (64 / POLY_LANES)), dim3(POLY_LANES), 0, h->stream,
+        hipLaunchKernelGGL(ransac_poly_kernel, dim3(B, chunk / POLY_LANES), dim3(POLY_LANES), 0, h->stream,
                            n1, n2, h->d_rstate, h->d_subsets, h->d_hyp, h->d_nmodels, mm, it);
-        hipLaunchKernelGGL(ransac_roots_kernel, dim3(B * wpp * (64 * RG / 256)), dim3(256), 0, h->stream,
-                           (const RpeRansacState *)h->d_rstate, (const double *)h->d_hyp, h->d_models, h->d_nmodels, B, wpp);
-        hipLaunchKernelGGL(ransac_score_kernel, dim3(B, wpp * (64 / SCORE_GROUP)), dim3(256), lds, h->stream,
+        hipLaunchKernelGGL(ransac_roots_kernel, dim3((unsigned)((long long)B * chunk * RG / 256)), dim3(256), 0, h->stream,
+                           (const RpeRansacState *)h->d_rstate, (const double *)h->d_hyp, h->d_models, h->d_nmodels, B, chunk);
+        hipLaunchKernelGGL(ransac_score_kernel, dim3(B, chunk / SCORE_GROUP), dim3(256), lds, h->stream,
                            n1, n2, (const RpeRansacState *)h->d_rstate, (const double *)h->d_models, (const int *)h->d_nmodels,
                            (const double *)h->d_K, h->cfg.ransac_threshold, h->d_counts, mm, use_lds);
         hipLaunchKernelGGL(ransac_update_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream,
@@ -829,7 +919,8 @@ void rpe_launch_ransac(rpe_handle *h, int B, bool want_mask)
                            (const double *)h->d_nit_denom, (const int *)h->d_nit_round, h->nit_num, h->d_E, h->d_found, chunk, B);
         done_iters += chunk;
         ++nlaunch;
-        if (nlaunch >= 2 && chunk < RPE_RANSAC_MAXCHUNK) chunk *= 2;
+        if (!env_sched.empty()) chunk = env_sched[std::min((size_t)nlaunch, env_sched.size() - 1)];
+        else chunk = kSchedule[std::min(nlaunch, 3)];
     }
     if (want_mask)
         hipLaunchKernelGGL(ransac_mask_kernel, dim3(B), dim3(256), 0, h->stream,
