@@ -64,7 +64,14 @@ void rpe_orb_upload_disc(const signed char *disc, int n)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int b = 0; b < 16; ++b) {
                         const int k = 32 * s + 16 * (lane >> 5) + b, j = 32 * nt + (lane & 31), d = k - off0 - j;
-                        if (k < 48 && d >= 0 && d <= 6) tb[((((size_t)off0 * 2 + s) * 2 + nt) * 64 + lane) * 16 + b] = tap[d];
+                        signed char v = 0;
+                        if (k < 48 && d >= 0 && d <= 6) v = (signed char)tap[d];
+                        // rows 48..51 carry the +128 * 257 that undoes the signed-byte offset of the pixels: the A operand
+                        // holds (127, 127, 127, 1) there, 127 * (127 + 127 + 5) + 3 = 32896 (the C operand stays the constant 0)
+                        else if (k == 48 || k == 49) v = 127;
+                        else if (k == 50) v = 5;
+                        else if (k == 51) v = 3;
+                        tb[((((size_t)off0 * 2 + s) * 2 + nt) * 64 + lane) * 16 + b] = v;
                     }
     hipMemcpyToSymbol(HIP_SYMBOL(c_blur_b), tb.data(), tb.size());
 }
@@ -880,8 +887,8 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
         // ---- horizontal pass on the matrix cores: hbuf column j <-> x = x0 - 19 + j (40 per row; the descriptor reaches
         // |dx| <= 18).  H[45 x 40] = P[45 x 48 raw bytes] . T[48 x 40] with the banded tap matrix T[k][j] = tap[k - off0 - j]
         // (tap = cvRound(256 g) = 18,34,49,55,49,34,18): 2 x 2 output tiles x 2 K-steps of v_mfma_i32_32x32x32_i8, exact
-        // integers.  The u8 pixels enter as signed bytes (p - 128, one v_xor per dword) and the accumulators start at
-        // 128 * 257, the tap sum's share of the offset.  The pass used to be 430 items x ~33 vector instructions (two
+        // integers.  The u8 pixels enter as signed bytes (p - 128, one v_xor per dword); the tap sum's share of the offset,
+        // 128 * 257, comes back through four spare K rows (see rpe_orb_upload_disc), so the C operand is the constant 0.  The pass used to be 430 items x ~33 vector instructions (two
         // v_dot4 per output plus the byte alignment) = 30 % of this issue-bound kernel; now the vector ALU only flips the
         // sign bits.  Accumulators go to LDS as u16 (<= 65535 = 255 * 257) with immediate-offset ds_write_b16.
         {
@@ -893,19 +900,17 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
             for (int sK = 0; sK < 2; ++sK)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) bop[sK][nt] = c_blur_b[((off0 * 2 + sK) * 2 + nt) * 64 + lane];
-            v16i_t cinit;                                       // loop-invariant C operand: 128 * (tap sum) in every element
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cinit[r] = 128 * 257;
+            const v16i_t czero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // C operand: the inline constant 0
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int arow = min(32 * mt + c32, KP_ROWS - 1);
                 v4i_t a0 = *(const v4i_t *)(rawb + arow * (KP_RAW_DW * 4) + 16 * hh);          // K-step 0: row bytes [16 hh, +16)
-                v4i_t a1 = {0, 0, 0, 0};                                                       // K-step 1: bytes [32 + 16 hh, +16), 48 per row
-                if (hh == 0) a1 = *(const v4i_t *)(rawb + arow * (KP_RAW_DW * 4) + 32);
+                v4i_t a1 = {(int)(0x017F7F7Fu ^ 0x80808080u), (int)0x80808080, (int)0x80808080, (int)0x80808080};   // K-step 1, k = 48..63: (127, 127, 127, 1, 0 ...) after the sign flip below
+                if (hh == 0) a1 = *(const v4i_t *)(rawb + arow * (KP_RAW_DW * 4) + 32);        // K-step 1: row bytes [32, 48)
                 a0 ^= (int)0x80808080; a1 ^= (int)0x80808080;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    v16i_t acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bop[0][nt], cinit, 0, 0, 0);
+                    v16i_t acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bop[0][nt], czero, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bop[1][nt], acc, 0, 0, 0);
                     const int colj = 32 * nt + c32;
                     if (colj < KP_HCOLS) {
@@ -917,8 +922,8 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
                         for (int gq = 0; gq < 4; ++gq) {
                             if (32 * mt + 8 * gq + 4 < KP_HROWS) {
                                 uint2 pk;
-                                pk.x = ((unsigned)acc[4 * gq] & 0xFFFFu) | ((unsigned)acc[4 * gq + 1] << 16);
-                                pk.y = ((unsigned)acc[4 * gq + 2] & 0xFFFFu) | ((unsigned)acc[4 * gq + 3] << 16);
+                                pk.x = __builtin_amdgcn_perm((unsigned)acc[4 * gq + 1], (unsigned)acc[4 * gq], 0x05040100u);      // low halves of two accumulators
+                                pk.y = __builtin_amdgcn_perm((unsigned)acc[4 * gq + 3], (unsigned)acc[4 * gq + 2], 0x05040100u);
                                 *(uint2 *)(dst + 8 * gq) = pk;
                             }
                         }
