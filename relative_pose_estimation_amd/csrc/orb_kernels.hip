@@ -240,6 +240,18 @@ void rpe_launch_pyramid(rpe_handle *h, int n_img)
 //           min3/max3, score = max(A,B)-1 (0 if not a corner) into the LDS score tile.
 //  phase 3: strict 3x3 maximum on the LDS score tile, 31-px border filter
 //           (KeyPointsFilter::runByImageBorder), 256-bin histogram, NMS map to HBM.
+// Inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts: 6 v_add_u32_dpp instead of 6 rounds of
+// ds_bpermute + select + add (~30 vector + LDS instructions).  Shifted-out lanes read the `old` operand, 0.
+__device__ __forceinline__ int wave_inclusive_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
 __device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
 __device__ __forceinline__ int imax3(int a, int b, int c) { return max(a, max(b, c)); }
 typedef short short2_t __attribute__((ext_vector_type(2)));
@@ -362,9 +374,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
     }
     {   // one append per tile: wave prefix sum of the per-lane counts, one LDS atomic per wave
         const int n = __popc(cand_bits);
-        int inc = n;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { int m = __shfl_up(inc, o); if (lane >= o) inc += m; }
+        const int inc = wave_inclusive_sum(n);
         const int total = __shfl(inc, 63);
         if (total) {
             int base = 0;
