@@ -278,7 +278,9 @@ int rpe_comm_barrier(rpe_comm *c);
  * instruction kind at `waves_per_simd` (1..8) resident waves per SIMD: the roof bench.py prices the VALU-bound
  * kernels against.  kind: 0 v_xor+v_bcnt (Hamming), 1 v_pk_min/max_i16 (FAST pair test), 2 v_perm_b32,
  * 3 v_dot4_u32_u8, 4 v_min3/v_max3_i32 (FAST score), 5 v_mad_u32_u24, 6 v_mul_f64+v_add_f64 (RANSAC, pose),
- * 7 v_fma_f64, 8 v_fma_f32, 9 v_pk_fma_f32 (the last two only to place the integer / f64 cadence next to the f32 one).
+ * 7 v_fma_f64, 8 v_fma_f32, 9 v_pk_fma_f32 (the last two only to place the integer / f64 cadence next to the f32 one),
+ * 10 v_dot2_u32_u16, 11 v_alignbyte_b32, 12 v_mul_lo_u32, 13 v_mad_u64_u32, 14 v_mul_u32_u24_sdwa, 15 v_pk_mad_u16
+ * (which instructions are full rate and which are not decides how the integer kernels are written).
  * rpe_calibrate_hbm: measured 16-B-per-lane streaming read rate (bytes/s). */
 int rpe_calibrate_valu(rpe_handle *h, int kind, int waves_per_simd, double *wave_insts_per_s);
 const char *rpe_calibrate_valu_name(int kind);

@@ -20,7 +20,7 @@ MATCH_CROSSCHECK, MATCH_RATIO = 0, 1
 # capacity flags (rpe_fetch_overflow)
 OVF_ORB_CANDIDATES, OVF_ORB_KEYPOINTS = 1 << 0, 1 << 1
 OVF_SIFT_SEEDS, OVF_SIFT_RAW, OVF_SIFT_PREFILTER, OVF_SIFT_CAP, OVF_SIFT_KEYPOINTS = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
-CALIB_KINDS = 10
+CALIB_KINDS = 16
 STAGE_COUNT = 12
 ORDER_BGR, ORDER_RGB = 0, 1
 

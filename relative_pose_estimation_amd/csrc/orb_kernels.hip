@@ -105,14 +105,10 @@ static inline unsigned xcd_image_grid(int nb, int n_img) { return (unsigned)(8 *
 // (<= 74 rows x 152 bytes, bounds derived arithmetically so the loads do not depend on
 // the coefficient tables; checked on the host) is staged in LDS with aligned dword loads, all of
 // them in flight before the first LDS store -- ~13 KB per workgroup.
-// One lane = 4 destination columns x 8 CONSECUTIVE destination rows.  The bilinear chain is separable in exact
+// One lane = 4 destination columns x 8 consecutive destination rows.  The bilinear chain is separable in exact
 // integer arithmetic: h(src row, dst col) = a0 p[o] + a1 p[o+1] (16 bits), out = (b0 h(top) + b1 h(bottom) + 2^15) >> 16.
-// At scale 1.1 consecutive destination rows share a source row (bottom of one = top of the next in 9 of 10 steps),
-// so a lane keeps the last bottom row's four h values and computes ~1.1 horizontal rows per output row instead of 2.
-// A horizontal row costs three aligned LDS dwords (the 4 columns span <= 6 source bytes), two v_alignbyte to
-// the lane's byte phase and two v_perm_b32 with per-lane selectors that gather p[o_j] and p[o_j + 1] of the
-// four columns -- instead of eight byte reads.  Reading p[o+1] unclamped is exact: the coefficient table gives
-// weight 0 wherever OpenCV clamps (last source column).
+// Reading p[o+1] and the row below unclamped is exact: the coefficient tables give weight 0 wherever OpenCV clamps
+// (last source column / row).  The row loop is described where it stands.
 #define PYR_TW 128
 #define PYR_ROWS 74
 #define PYR_DW 44                    // 176 B per window row = 11 x 16-B loads (origin aligned down to 16 B)
@@ -138,6 +134,9 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
     const int *cxp = coef + D.dcoef_off, *cyp = cxp + ((D.w + 127) & ~127);
     const int tx = tid & 31, ty8 = tid >> 5;
     const int x4 = x0 + 4 * tx;
+    // coefficient loads go out first, in the shadow of the window loads
+    const int4 cv = *(const int4 *)(cxp + x4);
+    const int4 r0v = *(const int4 *)(cyp + y0 + ty8 * 8), r1v = *(const int4 *)(cyp + y0 + ty8 * 8 + 4);
     {   // all window loads (16 B per lane) in flight before the first LDS store (one HBM round trip per tile):
         // lane -> 16-B column (tid & 15, 11 of 16 used) and rows (tid >> 4) + 16 q -- no divisions, one clamp per load
         constexpr int NQ = PYR_DW / 4, NLD = (PYR_ROWS + 15) / 16;
@@ -145,76 +144,80 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
         const uint8_t *colp = src + min(a0 + 16 * c, S.pitch - 16);      // pitch is a multiple of 16; clamped columns are never read
         uint4 stage[NLD];
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) stage[q] = *(const uint4 *)(colp + __umul24((unsigned)min(sy0 + r + 16 * q, S.h - 1), (unsigned)S.pitch));   // v_mul_lo_u32 is quarter rate
+        for (int q = 0; q < NLD; ++q) stage[q] = *(const uint4 *)(colp + __umul24((unsigned)min(sy0 + r + 16 * q, S.h - 1), (unsigned)S.pitch));
+        // pin the loads above the guarded stores: left alone the compiler sinks every load into the block of its store
+        // (load, s_waitcnt vmcnt(0), ds_write, next load ...: five dependent HBM round trips per workgroup instead of one)
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) asm volatile("" : "+v"(stage[q].x), "+v"(stage[q].y), "+v"(stage[q].z), "+v"(stage[q].w));
         if (c < NQ) {
 #pragma unroll
             for (int q = 0; q < NLD; ++q) { const int rr = r + 16 * q; if (rr < PYR_ROWS) ((uint4 *)s_src)[rr * NQ + c] = stage[q]; }
         }
     }
-    // per-lane column constants: source offsets o_j (non-decreasing, o_3 - o_0 <= 4), weights, byte selectors
-    int o[4], a1[4];
+    // per-lane column constants: source offsets o_j (non-decreasing, o_3 - o_0 <= 4) -> byte selectors, packed weights
+    typedef unsigned short v2u16_t __attribute__((ext_vector_type(2)));
+    unsigned selp[4];              // v_perm selector of column j: bytes (p[o_j], 0, p[o_j + 1], 0) of the 8 window bytes from o_0 on
+    v2u16_t apk[4];                // (256 - a1_j, a1_j)
+    int bcol;                      // window byte column of o_0
     {
-        const int4 cv = *(const int4 *)(cxp + x4);
-        o[0] = cv.x & 0xFFFF; a1[0] = cv.x >> 16; o[1] = cv.y & 0xFFFF; a1[1] = cv.y >> 16;
-        o[2] = cv.z & 0xFFFF; a1[2] = cv.z >> 16; o[3] = cv.w & 0xFFFF; a1[3] = cv.w >> 16;
-    }
-    const int bcol = o[0] - a0;                                 // window byte column of o_0
-    const int dw0 = bcol >> 2, sh = bcol & 3;
-    unsigned sel0 = 0, sel1 = 0;
+        const int cw[4] = {cv.x, cv.y, cv.z, cv.w};
+        const int o0 = cw[0] & 0xFFFF;
+        bcol = o0 - a0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned rel = (unsigned)min(max(o[j] - o[0], 0), 4);   // columns past D.w repeat the last entry: rel stays in range
-        sel0 |= rel << (8 * j);
-        sel1 |= (rel + 1u) << (8 * j);
+        for (int j = 0; j < 4; ++j) {
+            const unsigned rel = (unsigned)min(max((cw[j] & 0xFFFF) - o0, 0), 4);   // columns past D.w repeat the last entry: rel stays in range
+            selp[j] = 0x0c000c00u | rel | ((rel + 1u) << 16);
+            const unsigned a1 = (unsigned)cw[j] >> 16;
+            apk[j] = __builtin_bit_cast(v2u16_t, (256u - a1) | (a1 << 16));
+        }
     }
-    int oy[8], b1[8];
+    // per-lane row constants: LDS dword index of the top source row at the dword holding p[o_0], bottom-row weight
+    unsigned ra[8], b1[8];
     {
-        const int4 r0v = *(const int4 *)(cyp + y0 + ty8 * 8), r1v = *(const int4 *)(cyp + y0 + ty8 * 8 + 4);
         const int rv[8] = {r0v.x, r0v.y, r0v.z, r0v.w, r1v.x, r1v.y, r1v.z, r1v.w};
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) { oy[rr] = rv[rr] & 0xFFFF; b1[rr] = rv[rr] >> 16; }
+        for (int rr = 0; rr < 8; ++rr) { ra[rr] = __umul24((unsigned)((rv[rr] & 0xFFFF) - sy0), PYR_DW) + (unsigned)(bcol >> 2); b1[rr] = (unsigned)rv[rr] >> 16; }
+        // materialise them here: rematerialised inside the row loop, every row's first use of a table register sits behind an
+        // s_waitcnt vmcnt(0) -- which on gfx9 also waits for the previous row's global STORE (rows serialised on HBM write latency)
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) asm volatile("" : "+v"(ra[rr]), "+v"(b1[rr]));
     }
     __syncthreads();
     if (x4 >= D.pitch) return;
-    // horizontal pass of one source row for this lane's 4 columns
-    auto hrow = [&](int srow, unsigned (&hh)[4]) {
-        const unsigned *rw = s_src + __mul24(srow - sy0, PYR_DW) + dw0;
-        const unsigned d0 = rw[0], d1 = rw[1], d2 = rw[2];
-        const unsigned w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-        const unsigned p0 = __builtin_amdgcn_perm(w1, w0, sel0), p1 = __builtin_amdgcn_perm(w1, w0, sel1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)   // all factors fit 24 bits: v_mul_u32_u24 / v_mad_u32_u24 (full rate)
-            hh[j] = __umul24(256u - (unsigned)a1[j], (p0 >> (8 * j)) & 255u) + __umul24((unsigned)a1[j], (p1 >> (8 * j)) & 255u);
-    };
-    unsigned hc[4] = {0, 0, 0, 0};
-    int cached = -1;
+    // One output row = the horizontal pass of its two source rows + the vertical blend, no branches:
+    //   source row: three aligned LDS dwords from the one holding p[o_0] (the 4 columns span <= 6 bytes), two v_alignbyte to
+    //   the lane's byte phase; the bottom row is the top row + one window row -- where OpenCV clamps it (last source row)
+    //   its weight is 0 and the window holds finite bytes, so the unclamped read is exact;
+    //   column j: v_perm_b32 -> (p[o_j], p[o_j + 1]) as two u16, v_dot2_u32_u16 with (256 - a1_j, a1_j) -> h (16 bits);
+    //   out_j = (b0 h_top + b1 h_bot + 2^15) >> 16 by two 24-bit mads; the four results are byte 2 of four 24-bit sums.
+    // ~36 vector instructions per row of 4 pixels, and no divergent control flow; the version with a cached bottom row and
+    // separate byte extraction / multiplies took 62 (the kernel is bound by instruction issue: r02 trace, 0.21 G
+    // instructions in 0.33 ms on level 1).  (Byte-unaligned ds_read_b64 straight at p[o_0] saves the two v_alignbyte and
+    // was measured 70 % SLOWER: the LDS serialises misaligned 8-byte lanes.)
+    const unsigned sh = (unsigned)bcol & 3u;
     const unsigned colmask = x4 + 3 < D.w ? 0xFFFFFFFFu : (x4 >= D.w ? 0u : (0xFFFFFFFFu >> (8 * (x4 + 4 - D.w))));   // bytes past D.w stay 0
     uint8_t *dstp = base + D.off + __umul24((unsigned)(y0 + ty8 * 8), (unsigned)D.pitch) + x4;
+    const int nrows = min(8, D.h - (y0 + ty8 * 8));
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-        const int y = y0 + ty8 * 8 + rr;
-        if (y >= D.h) break;
-        const int top = oy[rr], bot = min(top + 1, S.h - 1);
-        unsigned ht[4];
-        if (top == cached) {
+        if (rr < nrows) {
+            const unsigned *rt = s_src + ra[rr], *rb = rt + PYR_DW;
+            const unsigned t0 = rt[0], t1 = rt[1], t2 = rt[2], u0 = rb[0], u1 = rb[1], u2 = rb[2];
+            uint2 vt, vb;
+            vt.x = __builtin_amdgcn_alignbyte(t1, t0, sh); vt.y = __builtin_amdgcn_alignbyte(t2, t1, sh);
+            vb.x = __builtin_amdgcn_alignbyte(u1, u0, sh); vb.y = __builtin_amdgcn_alignbyte(u2, u1, sh);
+            const unsigned b1u = b1[rr], b0u = 256u - b1u;
+            unsigned sm[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ht[j] = hc[j];
-        } else hrow(top, ht);
-        if (bot != top) hrow(bot, hc);
-        else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) hc[j] = ht[j];
+            for (int j = 0; j < 4; ++j) {
+                const unsigned ht = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, __builtin_amdgcn_perm(vt.y, vt.x, selp[j])), apk[j], 0u, false);
+                const unsigned hb = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, __builtin_amdgcn_perm(vb.y, vb.x, selp[j])), apk[j], 0u, false);
+                sm[j] = __umul24(b1u, hb) + (__umul24(b0u, ht) + 32768u);
+            }
+            const unsigned out = __builtin_amdgcn_perm(sm[1], sm[0], 0x0c0c0602u) | __builtin_amdgcn_perm(sm[3], sm[2], 0x06020c0cu);
+            *(unsigned *)dstp = out & colmask;
+            dstp += D.pitch;
         }
-        cached = bot;
-        const unsigned b1u = (unsigned)b1[rr], b0u = 256u - b1u;
-        // the four results are byte 2 of four 24-bit sums: two v_perm_b32 pick them (a shift/or chain makes the compiler
-        // turn the last column's 24-bit multiplies into quarter-rate v_mul_lo_u32 / v_mad_u64_u32)
-        unsigned sm[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sm[j] = __umul24(b0u, ht[j]) + __umul24(b1u, hc[j]) + 32768u;
-        const unsigned out = __builtin_amdgcn_perm(sm[1], sm[0], 0x0c0c0602u) | __builtin_amdgcn_perm(sm[3], sm[2], 0x06020c0cu);
-        *(unsigned *)dstp = out & colmask;
-        dstp += D.pitch;
     }
 }
 
@@ -306,6 +309,9 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
             const int y = min(max(y0 - 4 + r, 0), hgt - 1);
             stage[q] = *(const unsigned *)(src + (__umul24((unsigned)y, (unsigned)pitch) + (unsigned)lx));
         }
+        // pin the loads above the guarded stores (the compiler sinks a load into the block of its store: dependent round trips)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) asm volatile("" : "+v"(stage[q]));
 #pragma unroll
         for (int q = 0; q < 6; ++q) { const int r = lr + 14 * q; if (tid < 252 && r < 72) s_in[r * 18 + lc] = stage[q]; }
     }

@@ -935,8 +935,20 @@ __global__ __launch_bounds__(256) void valu_calib_kernel(unsigned *sink, int ite
                     asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d[u]) : "v"(dk));
                 else if (KIND == 8)  // v_fma_f32 (1 instruction): the guide's 2-cycle instruction
                     asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[u]) : "v"(fk));
-                else                 // v_pk_fma_f32 (1 instruction, 2 FMAs per lane): the 157 TFLOP/s f32 vector peak
+                else if (KIND == 9)  // v_pk_fma_f32 (1 instruction, 2 FMAs per lane): the 157 TFLOP/s f32 vector peak
                     asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(f2[u]) : "v"(fk2));
+                else if (KIND == 10) // pyramid / descriptor taps: v_dot2_u32_u16
+                    asm volatile("v_dot2_u32_u16 %0, %1, %2, %0" : "+v"(a[u]) : "v"(k0), "v"(k1));
+                else if (KIND == 11) // byte phase: v_alignbyte_b32
+                    asm volatile("v_alignbyte_b32 %0, %0, %1, %2" : "+v"(a[u]) : "v"(k0), "v"(k1));
+                else if (KIND == 12) // 32-bit multiply: v_mul_lo_u32
+                    asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[u]) : "v"(k0));
+                else if (KIND == 13) // 64-bit multiply-add (what 32-bit index arithmetic often compiles to): v_mad_u64_u32
+                    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d[u]) : "v"(k0), "v"(k1) : "vcc");
+                else if (KIND == 14) // SDWA operand select: v_mul_u32_u24_sdwa
+                    asm volatile("v_mul_u32_u24_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(a[u]) : "v"(k0));
+                else                 // packed 16-bit multiply-add: v_pk_mad_u16
+                    asm volatile("v_pk_mad_u16 %0, %0, %1, %2" : "+v"(a[u]) : "v"(k0), "v"(k1));
             }
         }
     }
@@ -946,14 +958,15 @@ __global__ __launch_bounds__(256) void valu_calib_kernel(unsigned *sink, int ite
     if (acc == 0x12345679u) *sink = acc;
 }
 
-static const int kCalibInstPerSlot[10] = {2, 2, 1, 1, 2, 1, 2, 1, 1, 1};
-static const char *kCalibNames[10] = {"v_xor_b32+v_bcnt_u32_b32", "v_pk_min_i16+v_pk_max_i16", "v_perm_b32", "v_dot4_u32_u8",
-                                      "v_min3_i32+v_max3_i32", "v_mad_u32_u24", "v_mul_f64+v_add_f64", "v_fma_f64", "v_fma_f32", "v_pk_fma_f32"};
-extern "C" const char *rpe_calibrate_valu_name(int kind) { return (kind >= 0 && kind < 10) ? kCalibNames[kind] : "?"; }
+static const int kCalibInstPerSlot[16] = {2, 2, 1, 1, 2, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+static const char *kCalibNames[16] = {"v_xor_b32+v_bcnt_u32_b32", "v_pk_min_i16+v_pk_max_i16", "v_perm_b32", "v_dot4_u32_u8",
+                                      "v_min3_i32+v_max3_i32", "v_mad_u32_u24", "v_mul_f64+v_add_f64", "v_fma_f64", "v_fma_f32", "v_pk_fma_f32",
+                                      "v_dot2_u32_u16", "v_alignbyte_b32", "v_mul_lo_u32", "v_mad_u64_u32", "v_mul_u32_u24_sdwa", "v_pk_mad_u16"};
+extern "C" const char *rpe_calibrate_valu_name(int kind) { return (kind >= 0 && kind < 16) ? kCalibNames[kind] : "?"; }
 
 extern "C" int rpe_calibrate_valu(rpe_handle *h, int kind, int waves_per_simd, double *wave_insts_per_s)
 {
-    if (!h || !wave_insts_per_s || kind < 0 || kind > 9 || waves_per_simd < 1 || waves_per_simd > 8) return RPE_ERR_INVALID;
+    if (!h || !wave_insts_per_s || kind < 0 || kind > 15 || waves_per_simd < 1 || waves_per_simd > 8) return RPE_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, h->cfg.device));
@@ -968,7 +981,7 @@ extern "C" int rpe_calibrate_valu(rpe_handle *h, int kind, int waves_per_simd, d
         switch (kind) {
 #define CALIB_CASE(K) case K: hipLaunchKernelGGL((valu_calib_kernel<K>), dim3(blocks), dim3(256), 0, h->stream, (unsigned *)h->d_hist, iters); break;
             CALIB_CASE(0) CALIB_CASE(1) CALIB_CASE(2) CALIB_CASE(3) CALIB_CASE(4) CALIB_CASE(5) CALIB_CASE(6) CALIB_CASE(7)
-            CALIB_CASE(8) CALIB_CASE(9)
+            CALIB_CASE(8) CALIB_CASE(9) CALIB_CASE(10) CALIB_CASE(11) CALIB_CASE(12) CALIB_CASE(13) CALIB_CASE(14) CALIB_CASE(15)
 #undef CALIB_CASE
         }
         HIPCHK(h, hipEventRecord(e1, h->stream));
