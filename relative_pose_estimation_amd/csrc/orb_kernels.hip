@@ -845,6 +845,8 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
     // contiguous bytes (three aligned ds_read_b64 instead of seven bank-conflicting ds_read_u16), and an MFMA lane, which
     // owns one column and 4 consecutive rows per register group, stores 8 bytes at a time
     __shared__ __attribute__((aligned(8))) unsigned s_hb[4][KP_HCOLS * KP_HSTRIDE / 2];
+    __shared__ int s_m[4][2];              // (m01, m10) of the four keypoints
+    __shared__ float s_ab[4][2];           // (cos, sin) of their angles
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int img, blk;
     if (!xcd_image_block(nb, n_img, img, blk)) return;
@@ -873,7 +875,6 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
         }
     }
     __syncthreads();
-    float a = 1.f, b = 0.f;
     if (active) {
         // ---- orb.cpp ICAngles: integer moments over the disc, reduced with wave shuffles
         // integer sums, so any summation order gives the oracle's moments: 4 disc pixels per packed-u8 dot product
@@ -897,14 +898,13 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
                 }
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
-        const float angle = fast_atan2_deg((float)m01, (float)m10);
-        if (lane == 0) kp_angle[g] = angle;
-        const float ang = angle * (float)(3.141592653589793238462643383279502884 / 180.0);
-        double sn, cs;
-        det_sincos((double)ang, sn, cs);
-        a = (float)cs; b = (float)sn;
+        // wave sums by DPP row shifts / broadcasts (total in lane 63, read back as a scalar): 12 + 2 instructions; six
+        // rounds of __shfl_xor were 36 vector + 12 LDS (ds_bpermute) instructions
+        m10 = __builtin_amdgcn_readlane(wave_inclusive_sum(m10), 63);
+        m01 = __builtin_amdgcn_readlane(wave_inclusive_sum(m01), 63);
+        // fastAtan2 and the deterministic sincos are ~100 vector instructions on wave-uniform values: the four keypoints
+        // of the workgroup get them from four LANES of wave 0 after the barrier below instead of from four waves
+        if (lane == 0) { s_m[wv][0] = m01; s_m[wv][1] = m10; }
         // ---- horizontal pass on the matrix cores: hbuf column j <-> x = x0 - 19 + j (40 per row; the descriptor reaches
         // |dx| <= 18).  H[45 x 40] = P[45 x 48 raw bytes] . T[48 x 40] with the banded tap matrix T[k][j] = tap[k - off0 - j]
         // (tap = cvRound(256 g) = 18,34,49,55,49,34,18): 2 x 2 output tiles x 2 K-steps of v_mfma_i32_32x32x32_i8, exact
@@ -954,7 +954,17 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
         }
     }
     __syncthreads();
+    if (wv == 0 && lane < 4 && blk * 4 + lane < nkp) {
+        const float angle = fast_atan2_deg((float)s_m[lane][0], (float)s_m[lane][1]);
+        kp_angle[(long long)img * lay.kcap + blk * 4 + lane] = angle;
+        const float ang = angle * (float)(3.141592653589793238462643383279502884 / 180.0);
+        double sn, cs;
+        det_sincos((double)ang, sn, cs);
+        s_ab[lane][0] = (float)cs; s_ab[lane][1] = (float)sn;
+    }
+    __syncthreads();
     if (!active) return;
+    const float a = s_ab[wv][0], b = s_ab[wv][1];
     // ---- orb.cpp computeOrbDescriptors: lane = 4 consecutive bit tests, vertical pass at the samples
     const uint8_t *hbytes = (const uint8_t *)hb;
     const float2 pt = kp_pt[g];
@@ -993,7 +1003,9 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
     }
     // 8 nibbles -> one dword (lanes 8m .. 8m+7), written by lane 8m
     unsigned v = nib << (4 * (lane & 7));
-    v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 4);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);       // quad_perm [1,0,3,2]: lane ^ 1
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);       // quad_perm [2,3,0,1]: lane ^ 2
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);      // row_half_mirror: the other quad of the 8
     if ((lane & 7) == 0) *(unsigned *)(desc + g * 32 + (lane >> 3) * 4) = v;
 }
 
