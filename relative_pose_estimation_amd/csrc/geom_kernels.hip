@@ -735,8 +735,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const double2 *__rest
             double2 a = sp1[i], b = sp2[i];
             cnt += sampson_inlier_fast(E, a.x, a.y, b.x, b.y, thr2, sbound);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        cnt = wave_sum(cnt);                             // DPP row shifts + v_readlane: 8 instructions instead of 6 ds_bpermute rounds
         if (lane == 0) counts[(slot0 + k) * RPE_MAX_MODELS + m] = cnt;
     }
 }
@@ -792,9 +791,7 @@ __global__ __launch_bounds__(256) void ransac_update_kernel(RpeRansacState *__re
                 if (c[m] > 4) cmax = max(cmax, c[m]);          // a model needs > max(best, 4) inliers to count
             }
             // exclusive prefix max over the lanes (iterations), seeded with the incoming best
-            int inc = cmax;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc = max(inc, v); }
+            const int inc = wave_inclusive_max(cmax);
             int pre = __shfl_up(inc, 1);
             if (lane == 0) pre = 0;
             pre = max(pre, best);
@@ -808,9 +805,7 @@ __global__ __launch_bounds__(256) void ransac_update_kernel(RpeRansacState *__re
                 }
             }
             // exclusive prefix min of niters
-            int pmin = lmin;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(pmin, o); if (lane >= o) pmin = min(pmin, v); }
+            const int pmin = wave_inclusive_min(lmin);
             int nit_before = __shfl_up(pmin, 1);
             if (lane == 0) nit_before = 0x7FFFFFFF;
             nit_before = min(nit_before, niters);
@@ -1077,10 +1072,7 @@ __global__ __launch_bounds__(256) void recover_pose_kernel(const double *__restr
         g3 += cheirality_one(R1, tn, x1, y1, x2, y2);
         g4 += cheirality_one(R2, tn, x1, y1, x2, y2);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        g1 += __shfl_xor(g1, o); g2 += __shfl_xor(g2, o); g3 += __shfl_xor(g3, o); g4 += __shfl_xor(g4, o);
-    }
+    g1 = wave_sum(g1); g2 = wave_sum(g2); g3 = wave_sum(g3); g4 = wave_sum(g4);
     if ((tid & 63) == 0) { atomicAdd(&s_g[0], g1); atomicAdd(&s_g[1], g2); atomicAdd(&s_g[2], g3); atomicAdd(&s_g[3], g4); }
     __syncthreads();
     if (tid == 0) {

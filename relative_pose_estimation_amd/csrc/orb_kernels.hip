@@ -243,18 +243,6 @@ void rpe_launch_pyramid(rpe_handle *h, int n_img)
 //           min3/max3, score = max(A,B)-1 (0 if not a corner) into the LDS score tile.
 //  phase 3: strict 3x3 maximum on the LDS score tile, 31-px border filter
 //           (KeyPointsFilter::runByImageBorder), 256-bin histogram, NMS map to HBM.
-// Inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts: 6 v_add_u32_dpp instead of 6 rounds of
-// ds_bpermute + select + add (~30 vector + LDS instructions).  Shifted-out lanes read the `old` operand, 0.
-__device__ __forceinline__ int wave_inclusive_sum(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);      // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);      // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);      // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);      // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);      // row_bcast:31 into rows 2 and 3
-    return v;
-}
 __device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
 __device__ __forceinline__ int imax3(int a, int b, int c) { return max(a, max(b, c)); }
 typedef short short2_t __attribute__((ext_vector_type(2)));
@@ -483,9 +471,7 @@ void rpe_launch_nms(rpe_handle *h, int n_img) { (void)h; (void)n_img; }   // fus
 __device__ __forceinline__ int block_excl_scan(int v, int *s_wave /*[5]*/, int &total)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(inc, o); if (lane >= o) inc += n; }
+    const int inc = wave_inclusive_sum(v);
     if (lane == 63) s_wave[wv] = inc;
     __syncthreads();
     int base = 0;
@@ -527,9 +513,7 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const unsigned *
         // wave 0: suffix sums over 256 bins, 4 bins per lane (descending)
         int b0 = 255 - 4 * tid;
         int c0 = hg[b0], c1 = hg[b0 - 1], c2 = hg[b0 - 2], c3 = hg[b0 - 3];
-        int s = c0 + c1 + c2 + c3, inc = s;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(inc, o); if (tid >= o) inc += n; }
+        int s = c0 + c1 + c2 + c3, inc = wave_inclusive_sum(s);
         int total = __shfl(inc, 63);
         int n2 = 2 * L.quota;
         int before = inc - s;
@@ -760,9 +744,7 @@ __global__ __launch_bounds__(64 * RPE_NLEVELS) void select_keypoints_kernel(cons
         const int b0 = 255 - 4 * lane;
         const int c0 = (int)hist[b0], c1 = (int)hist[b0 - 1], c2 = (int)hist[b0 - 2], c3 = (int)hist[b0 - 3];
         const int sum = c0 + c1 + c2 + c3;
-        int inc = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { int m = __shfl_up(inc, o); if (lane >= o) inc += m; }
+        const int inc = wave_inclusive_sum(sum);
         const int before = inc - sum;
         int fb = -1, fa = 0;
         if (before < kk && inc >= kk) {
@@ -782,8 +764,7 @@ __global__ __launch_bounds__(64 * RPE_NLEVELS) void select_keypoints_kernel(cons
     const unsigned thr_key = (n > q) ? prefix : 0u;
     int cnt = 0;
     for (int i = lane; i < n; i += 64) cnt += float_key(resp[i]) >= thr_key;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    cnt = wave_sum(cnt);
     if (lane == 0) s_cnt[l] = cnt;
     __syncthreads();
     int offset = 0, total = 0;
@@ -900,8 +881,8 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
         }
         // wave sums by DPP row shifts / broadcasts (total in lane 63, read back as a scalar): 12 + 2 instructions; six
         // rounds of __shfl_xor were 36 vector + 12 LDS (ds_bpermute) instructions
-        m10 = __builtin_amdgcn_readlane(wave_inclusive_sum(m10), 63);
-        m01 = __builtin_amdgcn_readlane(wave_inclusive_sum(m01), 63);
+        m10 = wave_sum(m10);
+        m01 = wave_sum(m01);
         // fastAtan2 and the deterministic sincos are ~100 vector instructions on wave-uniform values: the four keypoints
         // of the workgroup get them from four LANES of wave 0 after the barrier below instead of from four waves
         if (lane == 0) { s_m[wv][0] = m01; s_m[wv][1] = m10; }

@@ -52,6 +52,28 @@ __device__ __forceinline__ const uint8_t *rpe_level_base(const uint8_t *pyr, con
     return pyr + (long long)img * lay.stride + lay.lv[l].off;
 }
 
+// Inclusive prefix operations over the 64 lanes with DPP row shifts / row broadcasts: 6 v_<op>_dpp instead of 6 rounds of
+// ds_bpermute + select + op (~30 vector + LDS instructions).  Shifted-out lanes read the `old` operand, the identity.
+// The wave total is the value of lane 63 (__builtin_amdgcn_readlane(x, 63)).
+#define RPE_WAVE_SCAN(NAME, OP, IDENT)                                                                            \
+    __device__ __forceinline__ int NAME(int v)                                                                    \
+    {                                                                                                             \
+        v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x111, 0xF, 0xF, false));      /* row_shr:1 */            \
+        v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x112, 0xF, 0xF, false));      /* row_shr:2 */            \
+        v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x114, 0xF, 0xF, false));      /* row_shr:4 */            \
+        v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x118, 0xF, 0xF, false));      /* row_shr:8 */            \
+        v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x142, 0xA, 0xF, false));      /* row_bcast:15 -> rows 1, 3 */ \
+        v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x143, 0xC, 0xF, false));      /* row_bcast:31 -> rows 2, 3 */ \
+        return v;                                                                                                 \
+    }
+#define RPE_OP_ADD(a, b) ((a) + (b))
+#define RPE_OP_MAX(a, b) max((a), (b))
+#define RPE_OP_MIN(a, b) min((a), (b))
+RPE_WAVE_SCAN(wave_inclusive_sum, RPE_OP_ADD, 0)
+RPE_WAVE_SCAN(wave_inclusive_max, RPE_OP_MAX, (int)0x80000000)
+RPE_WAVE_SCAN(wave_inclusive_min, RPE_OP_MIN, 0x7FFFFFFF)
+__device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_inclusive_sum(v), 63); }
+
 struct RpeTile { short level, tx, ty, pad; };
 // 128x64 destination tile of the resize kernel: destination origin and origin of its source window in the level below
 struct RpePyrTile { short x0, y0, a0, sy0; };
