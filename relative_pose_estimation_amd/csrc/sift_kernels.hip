@@ -148,7 +148,37 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
     if (ti >= ntiles) return;
     const int x0 = (ti % tcols) * 64, y0 = (ti / tcols) * TH;
     const float *s = src + (long long)blockIdx.y * sstride;
-    if (w > R && h > R) {
+    constexpr int HAL = (R + 3) & ~3, NCH = (64 + 2 * HAL) / 4;            // interior fast path: 16-B chunks from x0 - HAL on
+    if (x0 >= HAL && x0 + 64 + HAL <= w && y0 >= R && y0 + TH + R <= h) {
+        // Interior tile (91 % of the tiles of a 3840 x 2160 octave): no reflection anywhere, so the window is fetched as
+        // global_load_dwordx4 chunks (4-byte aligned is all the hardware asks of a multi-dword load) -- 6 loads and ~100
+        // vector instructions per lane instead of 22 dword loads with ~20 instructions of index / reflection arithmetic
+        // each (the load phase was 44 % of this issue-bound kernel's instructions).
+        constexpr int NLD4 = (WINH * NCH + 255) / 256;
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        f4_t stage[NLD4];
+        const float *org = s + (size_t)(y0 - R) * w + (x0 - HAL);
+#pragma unroll
+        for (int q = 0; q < NLD4; ++q) {
+            const int i = min(tid + 256 * q, WINH * NCH - 1);
+            const int r = i / NCH, c4 = i - r * NCH;
+            const float *a = org + (size_t)r * w + 4 * c4;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stage[q]) : "v"(a) : "memory");      // kept in flight together
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < NLD4; ++q) {
+            asm volatile("" : "+v"(stage[q]));
+            const int i = tid + 256 * q;
+            const int r = i / NCH, c4 = i - r * NCH;
+            if (i < WINH * NCH) {
+                const int c = 4 * c4 - (HAL - R);                 // window column of the chunk's first element
+                float *d = s_src + r * SP + c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (c + e >= 0 && c + e < WIN) d[e] = stage[q][e];
+            }
+        }
+    } else if (w > R && h > R) {
         // window load, all requests in flight before the first LDS store: with one reflection being
         // enough (n > R; coordinates past n-1+R only feed outputs outside the image and are clamped)
         // the addresses are branch-free, so the loads are issued back to back instead of one
@@ -209,6 +239,11 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
 #pragma unroll
         for (int m = 0; m < 4 + 2 * R; ++m) { P[m].x = col[m * 64]; P[m].y = col[(m + 4) * 64]; }
         const int x = x0 + c;
+        // one 64-bit address per lane, rows by wave-uniform multiples of w (the per-output y * w + x in 64 bits was ~10
+        // instructions for each of the 16 stores)
+        const size_t o0 = (size_t)(y0 + 8 * g) * w + x;
+        float *pd = dst + ob + o0, *pg = dog ? dog + db + o0 : nullptr;
+        const int rows_left = x < w ? h - (y0 + 8 * g) : 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x2 acc = {0.f, 0.f};
@@ -216,11 +251,11 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
             for (int i = 0; i < KS; ++i) { const f32x2 kk = {k[i], k[i]}; acc += kk * P[j + i]; }
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                const int yy = 8 * g + j + 4 * hh, y = y0 + yy;
+                const int yl = j + 4 * hh, yy = 8 * g + yl;
                 const float a = hh ? acc.y : acc.x;
-                if (x < w && y < h) {
-                    dst[ob + (size_t)y * w + x] = a;
-                    if (dog) dog[db + (size_t)y * w + x] = a - s_src[(yy + R) * SP + c + R];
+                if (yl < rows_left) {
+                    pd[(size_t)yl * w] = a;
+                    if (pg) pg[(size_t)yl * w] = a - s_src[(yy + R) * SP + c + R];
                 }
             }
         }
