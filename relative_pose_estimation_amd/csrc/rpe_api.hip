@@ -297,7 +297,13 @@ static int alloc_workspace(rpe_handle *h)
     DM(h, h->d_desc, NI * L.kcap * h->desc_bytes);
     HIPCHK(h, hipMemset(h->d_kp_pt, 0, NI * L.kcap * sizeof(float2)));
     HIPCHK(h, hipMemset(h->d_kp_count, 0, NI * sizeof(int)));
-    DM(h, h->d_m_q, B * mm); DM(h, h->d_m_t, B * mm); DM(h, h->d_m_d, B * mm); DM(h, h->d_m_n, B);
+    DM(h, h->d_m_q, B * mm); DM(h, h->d_m_t, B * mm); DM(h, h->d_m_d, B * mm);
+    // results of a batch in ONE block [R 9B f64 | t 3B f64 | inliers B | status B | n_matches B]: rpe_fetch_results is one
+    // device-to-host copy into pinned memory (five copies into pageable memory left the GPU idle for ~100 us per step)
+    DM(h, h->d_resblk, (size_t)B * RPE_RESULT_BYTES);
+    h->d_R = (double *)h->d_resblk; h->d_t = h->d_R + (size_t)B * 9;
+    h->d_inliers = (int *)(h->d_t + (size_t)B * 3); h->d_status = h->d_inliers + B; h->d_m_n = h->d_status + B;
+    HIPCHK(h, hipHostMalloc((void **)&h->h_resblk, (size_t)B * RPE_RESULT_BYTES));
     DM(h, h->d_pts1, B * mm); DM(h, h->d_pts2, B * mm);
     if (h->cfg.norm_type == RPE_NORM_L2) DM(h, h->d_m_best, B * L.kcap);
     DM(h, h->d_n1, B * mm); DM(h, h->d_n2, B * mm);
@@ -307,8 +313,7 @@ static int alloc_workspace(rpe_handle *h)
     DM(h, h->d_nmodels, B * RPE_RANSAC_MAXCHUNK);
     DM(h, h->d_counts, B * RPE_RANSAC_MAXCHUNK * RPE_MAX_MODELS);
     DM(h, h->d_mask, B * mm);
-    DM(h, h->d_R, B * 9); DM(h, h->d_t, B * 3); DM(h, h->d_E, B * 9);
-    DM(h, h->d_inliers, B); DM(h, h->d_status, B);
+    DM(h, h->d_E, B * 9);
     DM(h, h->d_K, 9);
     return RPE_OK;
 }
@@ -368,10 +373,11 @@ extern "C" void rpe_destroy(rpe_handle *h)
     rpe_sift_destroy(h);
     void *ptrs[] = {h->d_tiles_full, h->d_tiles_fast, h->d_coef, h->d_pyr_tiles, h->d_pyr, h->d_bufA, h->d_tile_list, h->d_tile_cnt, h->d_stage1, h->d_stage2,
                     h->d_hist, h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_angle,
-                    h->d_kp_pt, h->d_kp_cs, h->d_kp_count, h->d_desc, h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2,
+                    h->d_kp_pt, h->d_kp_cs, h->d_kp_count, h->d_desc, h->d_m_q, h->d_m_t, h->d_m_d, h->d_resblk, h->d_pts1, h->d_pts2,
                     h->d_subsets, h->d_nit_denom, h->d_nit_round, h->d_rstate, h->d_n1, h->d_n2, h->d_found, h->d_models, h->d_hyp, h->d_counts,
-                    h->d_nmodels, h->d_mask, h->d_R, h->d_t, h->d_E, h->d_inliers, h->d_status, h->d_K, h->d_m_best, h->d_ovf};
+                    h->d_nmodels, h->d_mask, h->d_E, h->d_K, h->d_m_best, h->d_ovf};
     for (void *p : ptrs) if (p) hipFree(p);
+    if (h->h_resblk) hipHostFree(h->h_resblk);
     for (void *p : h->user_allocs) hipFree(p);
     for (int i = 0; i <= RPE_STAGE_COUNT; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
     for (int c = 0; c < 8; ++c) if (h->ev_up[c]) hipEventDestroy(h->ev_up[c]);
@@ -611,12 +617,22 @@ extern "C" int rpe_bgr_to_gray(rpe_handle *h, const uint8_t *h_bgr, size_t n_pix
 extern "C" int rpe_fetch_results(rpe_handle *h, int B, double *R, double *t, int32_t *inliers, int32_t *n_matches, int32_t *status)
 {
     if (!h || B < 1 || B > h->cfg.max_batch) return RPE_ERR_INVALID;
-    if (R) HIPCHK(h, hipMemcpyAsync(R, h->d_R, sizeof(double) * 9 * B, hipMemcpyDeviceToHost, h->stream));
-    if (t) HIPCHK(h, hipMemcpyAsync(t, h->d_t, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, h->stream));
-    if (inliers) HIPCHK(h, hipMemcpyAsync(inliers, h->d_inliers, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
-    if (n_matches) HIPCHK(h, hipMemcpyAsync(n_matches, h->d_m_n, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
-    if (status) HIPCHK(h, hipMemcpyAsync(status, h->d_status, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
+    const size_t MB = (size_t)h->cfg.max_batch;
+    // the used part of every section when the batch is small, the whole block in one piece otherwise
+    if ((size_t)B * 4 < MB) {
+        const uint8_t *d = h->d_resblk; uint8_t *o = h->h_resblk;
+        const size_t off[5] = {0, MB * 72, MB * 96, MB * 100, MB * 104}, len[5] = {(size_t)B * 72, (size_t)B * 24, (size_t)B * 4, (size_t)B * 4, (size_t)B * 4};
+        for (int k = 0; k < 5; ++k) HIPCHK(h, hipMemcpyAsync(o + off[k], d + off[k], len[k], hipMemcpyDeviceToHost, h->stream));
+    } else {
+        HIPCHK(h, hipMemcpyAsync(h->h_resblk, h->d_resblk, MB * RPE_RESULT_BYTES, hipMemcpyDeviceToHost, h->stream));
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint8_t *o = h->h_resblk;
+    if (R) memcpy(R, o, (size_t)B * 72);
+    if (t) memcpy(t, o + MB * 72, (size_t)B * 24);
+    if (inliers) memcpy(inliers, o + MB * 96, (size_t)B * 4);
+    if (status) memcpy(status, o + MB * 100, (size_t)B * 4);
+    if (n_matches) memcpy(n_matches, o + MB * 104, (size_t)B * 4);
     return RPE_OK;
 }
 

@@ -13,6 +13,7 @@
 #define RPE_RANSAC_CHUNK 64    // solver wave granularity: 64 RANSAC iterations per wave
 #define RPE_RANSAC_MAXCHUNK 512 // largest number of iterations evaluated per launch group (8 waves per pair)
 #define RPE_MAX_MODELS 10
+#define RPE_RESULT_BYTES 108     // per pair: R 72 + t 24 + inliers 4 + status 4 + n_matches 4
 #define RPE_FAST_TILE_CAP 1024 // entries of one 64x64 FAST tile list = the most strict 3x3 maxima a tile can hold
 
 // ---- HBM layout of one image's pyramid-shaped buffers ---------------------
@@ -153,6 +154,7 @@ struct rpe_handle {
     // results
     double *d_R = nullptr, *d_t = nullptr, *d_E = nullptr;
     int *d_inliers = nullptr, *d_status = nullptr;
+    uint8_t *d_resblk = nullptr, *h_resblk = nullptr;   // d_R, d_t, d_inliers, d_status, d_m_n live in d_resblk; pinned host mirror
     double *d_K = nullptr;
     // profiling
     bool profiling = false;
