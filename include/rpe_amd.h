@@ -154,7 +154,11 @@ int rpe_estimate_batch_device(rpe_handle *h, const uint8_t *d_imgs1, const uint8
                               const double K[9], double *R, double *t, int32_t *inliers,
                               int32_t *n_matches, int32_t *status);
 /* asynchronous form: enqueue on the handle's stream, results stay on the
- * device until rpe_fetch_results(); lets the host overlap the next upload. */
+ * device until rpe_fetch_results(); lets the host overlap the next upload.
+ * The image batches are READ IN PLACE by the ORB kernels (level 0 of the pyramid is the input itself when the
+ * width is a multiple of 16 and the batches are 16-byte aligned; other shapes are copied first): they must stay
+ * valid and unmodified until rpe_fetch_results() / rpe_synchronize() returns -- and until rpe_orb_debug_fetch()
+ * if that is called afterwards. */
 int rpe_enqueue_batch_device(rpe_handle *h, const uint8_t *d_imgs1, const uint8_t *d_imgs2, int B,
                              const double K[9]);
 int rpe_fetch_results(rpe_handle *h, int B, double *R, double *t, int32_t *inliers,

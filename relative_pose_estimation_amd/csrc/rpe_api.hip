@@ -484,7 +484,11 @@ static int run_orb(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na
 
 static int set_K(rpe_handle *h, const double K[9])
 {
-    HIPCHK(h, hipMemcpyAsync(h->d_K, K, sizeof(double) * 9, hipMemcpyHostToDevice, h->stream));
+    if (h->K_valid && memcmp(h->K_last, K, sizeof(double) * 9) == 0) return RPE_OK;      // same camera as the last batch: already resident
+    memcpy(h->K_last, K, sizeof(double) * 9);
+    h->K_valid = false;
+    HIPCHK(h, hipMemcpyAsync(h->d_K, h->K_last, sizeof(double) * 9, hipMemcpyHostToDevice, h->stream));
+    h->K_valid = true;
     return RPE_OK;
 }
 

@@ -154,6 +154,7 @@ struct rpe_handle {
     // results
     double *d_R = nullptr, *d_t = nullptr, *d_E = nullptr;
     int *d_inliers = nullptr, *d_status = nullptr;
+    double K_last[9] = {0}; bool K_valid = false;        // camera matrix resident in d_K (re-uploaded only when it changes)
     uint8_t *d_resblk = nullptr, *h_resblk = nullptr;   // d_R, d_t, d_inliers, d_status, d_m_n live in d_resblk; pinned host mirror
     double *d_K = nullptr;
     // profiling
