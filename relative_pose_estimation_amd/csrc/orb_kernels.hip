@@ -112,8 +112,9 @@ static inline unsigned xcd_image_grid(int nb, int n_img) { return (unsigned)(8 *
 #define PYR_TW 128
 #define PYR_ROWS 74
 #define PYR_DW 44                    // 176 B per window row = 11 x 16-B loads (origin aligned down to 16 B)
-__global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDeviceLayout lay, const int *__restrict__ coef,
-                                                          const RpePyrTile *__restrict__ ptiles, int ntiles, int l)
+#define PYR_THREADS 128               // two waves per 128x64 tile: 12 workgroups (156 KB of windows) per CU instead of 8 x four waves
+__global__ __launch_bounds__(PYR_THREADS) void pyr_resize_kernel(uint8_t *pyr, RpeDeviceLayout lay, const int *__restrict__ coef,
+                                                                  const RpePyrTile *__restrict__ ptiles, int ntiles, int l)
 {
     __shared__ __attribute__((aligned(16))) unsigned s_src[PYR_ROWS * PYR_DW + 4];   // +4: the unclamped p[o+1] of the last row's last column
     const RpeLevel &S = lay.lv[l - 1];
@@ -130,29 +131,35 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
     const uint8_t *src = rpe_level_base(pyr, lay, blockIdx.y, l - 1);
     // packed (offset | weight << 16) per destination column / row; the device table pads the x run to a multiple of 128
     // and the y run to a multiple of 64 entries (last entry replicated) and aligns both to 16 B, so a lane fetches its
-    // 4 columns with one 16-B load and its 8 rows with two, without clamps
+    // 4 columns with one 16-B load and 8 rows with two, without clamps
     const int *cxp = coef + D.dcoef_off, *cyp = cxp + ((D.w + 127) & ~127);
-    const int tx = tid & 31, ty8 = tid >> 5;
+    // The kernel lives on how many tile windows a CU keeps in flight (r02 diagnostic builds: loads + LDS alone 1.12 ms, rows +
+    // stores alone 1.26 ms, together 1.92 ms -- the phases of a workgroup overlap only through OTHER workgroups, and FAST
+    // run beside it on a second stream gained nothing: wave slots are the contended resource).  A lane therefore takes 4
+    // columns x TWO row groups of 8 rows: half the waves per window, 12 windows per CU, and the column constants serve 16 rows.
+    const int tx = tid & 31, ty8 = tid >> 5;               // row groups ty8 and ty8 + 4
     const int x4 = x0 + 4 * tx;
     // coefficient loads go out first, in the shadow of the window loads
     const int4 cv = *(const int4 *)(cxp + x4);
-    const int4 r0v = *(const int4 *)(cyp + y0 + ty8 * 8), r1v = *(const int4 *)(cyp + y0 + ty8 * 8 + 4);
+    int4 rq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rq[k] = *(const int4 *)(cyp + y0 + (ty8 + 4 * (k >> 1)) * 8 + 4 * (k & 1));
     {   // all window loads (16 B per lane) in flight before the first LDS store (one HBM round trip per tile):
-        // lane -> 16-B column (tid & 15, 11 of 16 used) and rows (tid >> 4) + 16 q -- no divisions, one clamp per load
-        constexpr int NQ = PYR_DW / 4, NLD = (PYR_ROWS + 15) / 16;
-        const int c = tid & 15, r = tid >> 4;
-        const uint8_t *colp = src + min(a0 + 16 * c, S.pitch - 16);      // pitch is a multiple of 16; clamped columns are never read
+        // chunk i = tid + 128 q of the 74 x 11 chunks of the window, row i / 11, 16-B column i % 11
+        constexpr int NQ = PYR_DW / 4, NCHUNK = PYR_ROWS * NQ, NLD = (NCHUNK + PYR_THREADS - 1) / PYR_THREADS;
         uint4 stage[NLD];
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) stage[q] = *(const uint4 *)(colp + __umul24((unsigned)min(sy0 + r + 16 * q, S.h - 1), (unsigned)S.pitch));
+        for (int q = 0; q < NLD; ++q) {
+            const int i = min(tid + PYR_THREADS * q, NCHUNK - 1);
+            const int r = i / NQ, c = i - r * NQ;
+            stage[q] = *(const uint4 *)(src + min(a0 + 16 * c, S.pitch - 16) + __umul24((unsigned)min(sy0 + r, S.h - 1), (unsigned)S.pitch));   // pitch is a multiple of 16; clamped columns are never read
+        }
         // pin the loads above the guarded stores: left alone the compiler sinks every load into the block of its store
-        // (load, s_waitcnt vmcnt(0), ds_write, next load ...: five dependent HBM round trips per workgroup instead of one)
+        // (load, s_waitcnt vmcnt(0), ds_write, next load ...: dependent HBM round trips instead of one)
 #pragma unroll
         for (int q = 0; q < NLD; ++q) asm volatile("" : "+v"(stage[q].x), "+v"(stage[q].y), "+v"(stage[q].z), "+v"(stage[q].w));
-        if (c < NQ) {
 #pragma unroll
-            for (int q = 0; q < NLD; ++q) { const int rr = r + 16 * q; if (rr < PYR_ROWS) ((uint4 *)s_src)[rr * NQ + c] = stage[q]; }
-        }
+        for (int q = 0; q < NLD; ++q) { const int i = tid + PYR_THREADS * q; if (i < NCHUNK) ((uint4 *)s_src)[i] = stage[q]; }
     }
     // per-lane column constants: source offsets o_j (non-decreasing, o_3 - o_0 <= 4) -> byte selectors, packed weights
     typedef unsigned short v2u16_t __attribute__((ext_vector_type(2)));
@@ -171,16 +178,19 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
             apk[j] = __builtin_bit_cast(v2u16_t, (256u - a1) | (a1 << 16));
         }
     }
-    // per-lane row constants: LDS dword index of the top source row at the dword holding p[o_0], bottom-row weight
-    unsigned ra[8], b1[8];
+    // per-lane row constants, packed (LDS dword index of the top source row at the dword holding p[o_0]) | (bottom-row
+    // weight << 16).  Materialised here: rematerialised inside the row loop, every row's first use of a table register sits
+    // behind an s_waitcnt vmcnt(0) -- which on gfx9 also waits for the previous row's global STORE (rows serialised on HBM
+    // write latency)
+    unsigned rc[16];
     {
-        const int rv[8] = {r0v.x, r0v.y, r0v.z, r0v.w, r1v.x, r1v.y, r1v.z, r1v.w};
+        const int rv[16] = {rq[0].x, rq[0].y, rq[0].z, rq[0].w, rq[1].x, rq[1].y, rq[1].z, rq[1].w,
+                            rq[2].x, rq[2].y, rq[2].z, rq[2].w, rq[3].x, rq[3].y, rq[3].z, rq[3].w};
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) { ra[rr] = __umul24((unsigned)((rv[rr] & 0xFFFF) - sy0), PYR_DW) + (unsigned)(bcol >> 2); b1[rr] = (unsigned)rv[rr] >> 16; }
-        // materialise them here: rematerialised inside the row loop, every row's first use of a table register sits behind an
-        // s_waitcnt vmcnt(0) -- which on gfx9 also waits for the previous row's global STORE (rows serialised on HBM write latency)
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) asm volatile("" : "+v"(ra[rr]), "+v"(b1[rr]));
+        for (int rr = 0; rr < 16; ++rr) {
+            rc[rr] = (__umul24((unsigned)((rv[rr] & 0xFFFF) - sy0), PYR_DW) + (unsigned)(bcol >> 2)) | ((unsigned)rv[rr] & 0xFFFF0000u);
+            asm volatile("" : "+v"(rc[rr]));
+        }
     }
     __syncthreads();
     if (x4 >= D.pitch) return;
@@ -190,33 +200,37 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t *pyr, RpeDevice
     //   its weight is 0 and the window holds finite bytes, so the unclamped read is exact;
     //   column j: v_perm_b32 -> (p[o_j], p[o_j + 1]) as two u16, v_dot2_u32_u16 with (256 - a1_j, a1_j) -> h (16 bits);
     //   out_j = (b0 h_top + b1 h_bot + 2^15) >> 16 by two 24-bit mads; the four results are byte 2 of four 24-bit sums.
-    // ~36 vector instructions per row of 4 pixels, and no divergent control flow; the version with a cached bottom row and
-    // separate byte extraction / multiplies took 62 (the kernel is bound by instruction issue: r02 trace, 0.21 G
-    // instructions in 0.33 ms on level 1).  (Byte-unaligned ds_read_b64 straight at p[o_0] saves the two v_alignbyte and
-    // was measured 70 % SLOWER: the LDS serialises misaligned 8-byte lanes.)
+    // ~38 vector instructions per row of 4 pixels, and no divergent control flow; the version with a cached bottom row and
+    // separate byte extraction / multiplies took 62.  (Byte-unaligned ds_read_b64 straight at p[o_0] saves the two
+    // v_alignbyte and was measured 70 % SLOWER: the LDS serialises misaligned 8-byte lanes.)
     const unsigned sh = (unsigned)bcol & 3u;
     const unsigned colmask = x4 + 3 < D.w ? 0xFFFFFFFFu : (x4 >= D.w ? 0u : (0xFFFFFFFFu >> (8 * (x4 + 4 - D.w))));   // bytes past D.w stay 0
-    uint8_t *dstp = base + D.off + __umul24((unsigned)(y0 + ty8 * 8), (unsigned)D.pitch) + x4;
-    const int nrows = min(8, D.h - (y0 + ty8 * 8));
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        if (rr < nrows) {
-            const unsigned *rt = s_src + ra[rr], *rb = rt + PYR_DW;
-            const unsigned t0 = rt[0], t1 = rt[1], t2 = rt[2], u0 = rb[0], u1 = rb[1], u2 = rb[2];
-            uint2 vt, vb;
-            vt.x = __builtin_amdgcn_alignbyte(t1, t0, sh); vt.y = __builtin_amdgcn_alignbyte(t2, t1, sh);
-            vb.x = __builtin_amdgcn_alignbyte(u1, u0, sh); vb.y = __builtin_amdgcn_alignbyte(u2, u1, sh);
-            const unsigned b1u = b1[rr], b0u = 256u - b1u;
-            unsigned sm[4];
+    for (int half = 0; half < 2; ++half) {
+        const int yb = y0 + (ty8 + 4 * half) * 8;
+        uint8_t *dstp = base + D.off + __umul24((unsigned)yb, (unsigned)D.pitch) + x4;
+        const int nrows = min(8, D.h - yb);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned ht = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, __builtin_amdgcn_perm(vt.y, vt.x, selp[j])), apk[j], 0u, false);
-                const unsigned hb = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, __builtin_amdgcn_perm(vb.y, vb.x, selp[j])), apk[j], 0u, false);
-                sm[j] = __umul24(b1u, hb) + (__umul24(b0u, ht) + 32768u);
+        for (int r8 = 0; r8 < 8; ++r8) {
+            if (r8 < nrows) {
+                const unsigned rcv = rc[8 * half + r8];
+                const unsigned *rt = s_src + (rcv & 0xFFFFu), *rb = rt + PYR_DW;
+                const unsigned t0 = rt[0], t1 = rt[1], t2 = rt[2], u0 = rb[0], u1 = rb[1], u2 = rb[2];
+                uint2 vt, vb;
+                vt.x = __builtin_amdgcn_alignbyte(t1, t0, sh); vt.y = __builtin_amdgcn_alignbyte(t2, t1, sh);
+                vb.x = __builtin_amdgcn_alignbyte(u1, u0, sh); vb.y = __builtin_amdgcn_alignbyte(u2, u1, sh);
+                const unsigned b1u = rcv >> 16, b0u = 256u - b1u;
+                unsigned sm[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned ht = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, __builtin_amdgcn_perm(vt.y, vt.x, selp[j])), apk[j], 0u, false);
+                    const unsigned hb = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, __builtin_amdgcn_perm(vb.y, vb.x, selp[j])), apk[j], 0u, false);
+                    sm[j] = __umul24(b1u, hb) + (__umul24(b0u, ht) + 32768u);
+                }
+                const unsigned out = __builtin_amdgcn_perm(sm[1], sm[0], 0x0c0c0602u) | __builtin_amdgcn_perm(sm[3], sm[2], 0x06020c0cu);
+                *(unsigned *)dstp = out & colmask;
+                dstp += D.pitch;
             }
-            const unsigned out = __builtin_amdgcn_perm(sm[1], sm[0], 0x0c0c0602u) | __builtin_amdgcn_perm(sm[3], sm[2], 0x06020c0cu);
-            *(unsigned *)dstp = out & colmask;
-            dstp += D.pitch;
         }
     }
 }
@@ -225,7 +239,7 @@ void rpe_launch_pyramid(rpe_handle *h, int n_img)
 {
     for (int l = 1; l < RPE_NLEVELS; ++l) {
         const int nt = h->pyr_tile_cnt[l];
-        hipLaunchKernelGGL(pyr_resize_kernel, dim3((nt + 7) / 8 * 8, n_img), dim3(256), 0, h->stream, h->d_pyr, h->lay, h->d_coef,
+        hipLaunchKernelGGL(pyr_resize_kernel, dim3((nt + 7) / 8 * 8, n_img), dim3(PYR_THREADS), 0, h->stream, h->d_pyr, h->lay, h->d_coef,
                            (const RpePyrTile *)(h->d_pyr_tiles + h->pyr_tile_off[l]), nt, l);
     }
 }
