@@ -443,11 +443,15 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
             const int cc = s_cand[i];
             const int bx = cc & 127, ry = cc >> 7;
             const int px = x0 - 4 + bx, py = y0 - 1 + ry;
-            const bool inside = bx >= 4 && bx < 68 && ry >= 1 && ry <= 64 &&                      // halo pixels are not outputs
-                                px >= RPE_EDGE && px < w - RPE_EDGE && py >= RPE_EDGE && py < hgt - RPE_EDGE;
+            // branch-free: the eight neighbour reads go out together (as a short-circuit chain they were nine dependent LDS
+            // round trips with an exec-mask save / restore each); reads of halo candidates past the score tile land in
+            // other LDS arrays of this kernel and are discarded by `inside`
+            const bool inside = (unsigned)(bx - 4) < 64u & (unsigned)(ry - 1) < 64u &                 // halo pixels are not outputs
+                                (unsigned)(px - RPE_EDGE) < (unsigned)(w - 2 * RPE_EDGE) & (unsigned)(py - RPE_EDGE) < (unsigned)(hgt - 2 * RPE_EDGE);
             const uint8_t *q = sc + ry * 72 + bx;
             const int v = q[0];
-            if (inside && v != 0 && v > q[-1] && v > q[1] && v > q[-73] && v > q[-72] && v > q[-71] && v > q[71] && v > q[72] && v > q[73]) {
+            const int nmax = imax3(imax3(q[-1], q[1], q[-73]), imax3(q[-72], q[-71], q[71]), max((int)q[72], (int)q[73]));
+            if (inside & (v != 0) & (v > nmax)) {
                 keep = true;
                 ent = ((unsigned)v << 24) | ((unsigned)py << 12) | (unsigned)px;
                 atomicAdd(&s_hist[v], 1u);
