@@ -840,14 +840,17 @@ __global__ __launch_bounds__(256) void sift_finalize_kernel(const float *__restr
 }
 
 // ---------------------------------------------------------------- descriptor
-__global__ __launch_bounds__(256) void sift_describe_kernel(const float *__restrict__ gauss, SiftDev dv, const float *__restrict__ fin,
+// One keypoint per 64-lane workgroup: the 15 KB of accumulators per keypoint decide the occupancy (four keypoints per
+// workgroup were 61 KB: 2 workgroups = 8 waves per CU; one per workgroup gives 10).
+#define SIFT_DESC_KPW 1
+__global__ __launch_bounds__(64 * SIFT_DESC_KPW) void sift_describe_kernel(const float *__restrict__ gauss, SiftDev dv, const float *__restrict__ fin,
                                                              const int *__restrict__ kp_count, uint8_t *__restrict__ desc)
 {
-    __shared__ float s_part[4][360][8];
-    __shared__ float s_hist[4][360];
-    __shared__ float s_stage[4][64 * 9];
+    __shared__ float s_part[SIFT_DESC_KPW][360][8];
+    __shared__ float s_hist[SIFT_DESC_KPW][360];
+    __shared__ float s_stage[SIFT_DESC_KPW][64 * 9];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int kidx = blockIdx.x * 4 + wv, img = blockIdx.y;
+    const int kidx = blockIdx.x * SIFT_DESC_KPW + wv, img = blockIdx.y;
     if (kidx >= kp_count[img]) return;
     const float *f = fin + ((long long)img * dv.kcap + kidx) * 6;
     const int koct = __float_as_int(f[5]);
@@ -1174,7 +1177,7 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
                        S->d_fin, h->d_kp_pt, h->d_kp_count, h->d_ovf);
     // 6. descriptors
     MARK(h, RPE_STAGE_ANGLE); MARK(h, RPE_STAGE_BLUR); MARK(h, RPE_STAGE_DESCRIBE);
-    hipLaunchKernelGGL(sift_describe_kernel, dim3((dv.kcap + 3) / 4, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
+    hipLaunchKernelGGL(sift_describe_kernel, dim3((dv.kcap + SIFT_DESC_KPW - 1) / SIFT_DESC_KPW, n), dim3(64 * SIFT_DESC_KPW), 0, h->stream, (const float *)S->d_gauss, dv,
                        (const float *)S->d_fin, (const int *)h->d_kp_count, h->d_desc);
     SCHK(hipGetLastError());
     return RPE_OK;
