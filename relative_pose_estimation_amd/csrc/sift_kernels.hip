@@ -136,8 +136,9 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
                                                                long long dstride, float *__restrict__ dog, long long dogstride,
                                                                int w, int h, int kid, int tcols, int ntiles)
 {
-    // TH = tile height (64 or 32): the LDS footprint (WINH x (SP + 64) floats) decides how many workgroups a CU holds;
-    // at R >= 8 a 64-row tile leaves 2 per CU and the kernel waits on its own window loads, a 32-row tile fits 4
+    // TH = tile height: the LDS footprint (WINH x (SP + 64) floats) decides how many workgroups a CU holds; at R >= 8 a
+    // 64-row tile leaves 2 per CU and the kernel waits on its own window loads, a 32-row tile fits 4 (and 6 at R = 5, 6,
+    // where it measured 1.5 % faster than 64 rows despite the taller halo)
     constexpr int WIN = 64 + 2 * R, WINH = TH + 2 * R, SP = WIN + 1, KS = 2 * R + 1;
     __shared__ float s_src[WINH * SP];
     __shared__ float s_tmp[WINH * 64];
@@ -558,6 +559,7 @@ __global__ __launch_bounds__(256) void sift_adjust_kernel(const float *__restric
     q[1] = xi; q[2] = xr; q[3] = xc; q[4] = contr;
 }
 
+// (112 VGPRs = 4 waves per SIMD; forcing 5, 6 or 8 through __launch_bounds__ changed nothing: 22.2 -> 21.5 / 22.2 / 23.0 ms)
 __global__ __launch_bounds__(256) void sift_orient_kernel(const float *__restrict__ gauss, SiftDev dv,
                                                            const float *__restrict__ surv, const int *__restrict__ nsurv,
                                                            float *__restrict__ raw, int *__restrict__ nraw, unsigned *__restrict__ overflow)
@@ -1091,7 +1093,7 @@ template <int R>
 static void sift_blur_launch(rpe_handle *h, const float *src, long long sstride, float *dst, long long dstride, float *dog,
                              long long dogstride, int w, int hh, int kid, int n_img)
 {
-    constexpr int TH = R >= 8 ? 32 : 64;
+    constexpr int TH = 32;
     const int tcols = (w + 63) / 64, ntiles = tcols * ((hh + TH - 1) / TH);
     hipLaunchKernelGGL((sift_blur_fused_kernel<R, TH>), dim3((ntiles + 7) / 8 * 8, n_img), dim3(256), 0, h->stream, src, sstride, dst, dstride, dog, dogstride,
                        w, hh, kid, tcols, ntiles);
