@@ -330,6 +330,23 @@ def test_level0_in_place_and_copied_agree(capi, K_vga):
     e.close()
 
 
+def test_result_block_fetch_paths(capi, K_vga):
+    """rpe_fetch_results copies the single result block [R | t | inliers | status | n_matches] to pinned memory in one piece,
+    or only the used part of every section when the batch is small against max_batch: both give what a tight handle gives."""
+    from relative_pose_estimation_amd import synthetic
+    i1, i2, _, _ = synthetic.make_batch(3, K_vga, cfg=2)
+    tight = capi.Engine(640, 480, max_batch=3, nfeatures=1000, max_matches=500)
+    ref = tight.estimate_batch(i1, i2, K_vga)
+    tight.close()
+    wide = capi.Engine(640, 480, max_batch=16, nfeatures=1000, max_matches=500)       # 3 * 4 < 16: section copies
+    got = wide.estimate_batch(i1, i2, K_vga)
+    got2 = wide.estimate_batch(np.concatenate([i1, i1]), np.concatenate([i2, i2]), K_vga)   # 6 * 4 >= 16: whole block
+    wide.close()
+    for a, b, c in zip(ref, got, got2):
+        assert np.array_equal(a, b) and np.array_equal(a, c[:3]) and np.array_equal(a, c[3:])
+    assert (ref[4] == 0).all()
+
+
 # ------------------------------------------------------------------ roofline calibration entry points
 def test_calibration_entry_points(capi):
     """rpe_calibrate_valu / rpe_calibrate_hbm run and give physically possible rates: integer and f64 instructions issue
