@@ -256,7 +256,7 @@ void rpe_launch_pyramid(rpe_handle *h, int n_img)
 //  phase 2: list processed densely: 16 ring differences, window-9 min/max via
 //           min3/max3, score = max(A,B)-1 (0 if not a corner) into the LDS score tile.
 //  phase 3: strict 3x3 maximum on the LDS score tile, 31-px border filter
-//           (KeyPointsFilter::runByImageBorder), 256-bin histogram, NMS map to HBM.
+//           (KeyPointsFilter::runByImageBorder), 256-bin histogram, per-tile keypoint list to HBM.
 __device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
 __device__ __forceinline__ int imax3(int a, int b, int c) { return max(a, max(b, c)); }
 typedef short short2_t __attribute__((ext_vector_type(2)));
@@ -908,9 +908,10 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
         // |dx| <= 18).  H[45 x 40] = P[45 x 48 raw bytes] . T[48 x 40] with the banded tap matrix T[k][j] = tap[k - off0 - j]
         // (tap = cvRound(256 g) = 18,34,49,55,49,34,18): 2 x 2 output tiles x 2 K-steps of v_mfma_i32_32x32x32_i8, exact
         // integers.  The u8 pixels enter as signed bytes (p - 128, one v_xor per dword); the tap sum's share of the offset,
-        // 128 * 257, comes back through four spare K rows (see rpe_orb_upload_disc), so the C operand is the constant 0.  The pass used to be 430 items x ~33 vector instructions (two
-        // v_dot4 per output plus the byte alignment) = 30 % of this issue-bound kernel; now the vector ALU only flips the
-        // sign bits.  Accumulators go to LDS as u16 (<= 65535 = 255 * 257) with immediate-offset ds_write_b16.
+        // 128 * 257, comes back through four spare K rows (see rpe_orb_upload_disc), so the C operand is the constant 0.
+        // The pass used to be 430 items x ~33 vector instructions (two v_dot4 per output plus the byte alignment) = 30 % of
+        // this kernel's instructions; now the vector ALU only flips the sign bits.  Accumulators go to the column-major LDS
+        // buffer as u16 (<= 65535 = 255 * 257), four rows per ds_write_b64.
         {
             const int hh = lane >> 5, c32 = lane & 31;
             const uint8_t *rawb = (const uint8_t *)raw;
