@@ -341,16 +341,19 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
         // are gathered by one v_perm and dropped into place by a shift and a v_and_or: 5 instructions per row instead of
         // 14 for the compact 4-bit form; the x-validity mask is applied once, spread to bytes)
         const unsigned vmask5 = ((vmask * 0x00204081u) & 0x01010101u) * 0x1Fu;
+        const unsigned *pC = s_in + (r0 + 3) * 18 + c, *pL = s_in + (r0 + 3) * 18 + cl, *pR = s_in + (r0 + 3) * 18 + cr;
 #pragma unroll
         for (int it = 0; it < 5; ++it) {
             const int ry = r0 + 14 * it;
             const int py = y0 - 1 + ry;
             if (vmask == 0 || ry >= FS_ROWS || py < RPE_EDGE - 1 || py >= hgt - RPE_EDGE + 1) continue;
-            const int ri = ry + 3;                       // input row of this score row
-            const unsigned cdw = s_in[ri * 18 + c], ldw = s_in[ri * 18 + cl], rdw = s_in[ri * 18 + cr];
-            const unsigned upl = s_in[(ri - 2) * 18 + cl], upc = s_in[(ri - 2) * 18 + c], upr = s_in[(ri - 2) * 18 + cr];
-            const unsigned dnl = s_in[(ri + 2) * 18 + cl], dnc = s_in[(ri + 2) * 18 + c], dnr = s_in[(ri + 2) * 18 + cr];
-            const unsigned bot = s_in[(ri + 3) * 18 + c], top = s_in[(ri - 3) * 18 + c];
+            // input row of this score row = ry + 3; the three column pointers are per-lane constants, the rows compile-time
+            // offsets from them (ds_read immediate offsets instead of six address instructions per row)
+            const int ro = 14 * 18 * it;
+            const unsigned cdw = pC[ro], ldw = pL[ro], rdw = pR[ro];
+            const unsigned upl = pL[ro - 36], upc = pC[ro - 36], upr = pR[ro - 36];
+            const unsigned dnl = pL[ro + 36], dnc = pC[ro + 36], dnr = pR[ro + 36];
+            const unsigned bot = pC[ro + 54], top = pC[ro - 54];
             unsigned z[2];
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
