@@ -831,30 +831,36 @@ void rpe_launch_keypoints(rpe_handle *h, int n_img)
 // touch, (3) the vertical pass evaluated only at the 512 steered sampling points.
 // Integer results are identical to blurring the whole level (the patch never reaches
 // the image border: keypoints are >= 31 px inside, the footprint is 22 px).
+// keypoints (waves) per workgroup.  The phases of a keypoint (patch fetch 0.88 ms, moments + MFMA blur 0.36 ms, steered
+// sampling 0.65 ms when run alone -- diagnostic builds) overlap only through OTHER waves, and barriers that tie four
+// keypoints together cost more than the shared angle / sincos evaluation saves: 4 per workgroup 2.25 ms, 2: 2.25, 1: 2.17.
+#ifndef KP_PER_WG
+#define KP_PER_WG 1
+#endif
 #define KP_R 22
 #define KP_ROWS 45
 #define KP_RAW_DW 12                 // 48 bytes per raw row
 #define KP_HCOLS 40                  // horizontally blurred columns: x = x0 - 19 + j
 #define KP_HROWS 48                  // rows per column of the blurred buffer (45 + 3 of padding for the unpredicated MFMA tile stores)
 #define KP_HSTRIDE 52                // u16 per column (104 B: 48 rows + 8 B; 26 dwords, so the 16 lanes of a ds_write_b64 group hit 16 distinct bank pairs)
-__global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__restrict__ pyr, const unsigned *__restrict__ kp_xy,
+__global__ __launch_bounds__(64 * KP_PER_WG) void orient_describe_kernel(const uint8_t *__restrict__ pyr, const unsigned *__restrict__ kp_xy,
                                                                const float2 *__restrict__ kp_pt, const int *__restrict__ kp_count,
                                                                float *__restrict__ kp_angle, uint8_t *__restrict__ desc,
                                                                RpeDeviceLayout lay, int nb, int n_img)
 {
-    __shared__ __attribute__((aligned(16))) unsigned s_raw[4][KP_ROWS * KP_RAW_DW];   // 2160 B per wave: 16-B aligned rows of 48 B
+    __shared__ __attribute__((aligned(16))) unsigned s_raw[KP_PER_WG][KP_ROWS * KP_RAW_DW];   // 2160 B per wave: 16-B aligned rows of 48 B
     // horizontally blurred patch, COLUMN-major u16 [column][row]: the 7 vertical taps of a steered sample are 14
     // contiguous bytes (three aligned ds_read_b64 instead of seven bank-conflicting ds_read_u16), and an MFMA lane, which
     // owns one column and 4 consecutive rows per register group, stores 8 bytes at a time
-    __shared__ __attribute__((aligned(8))) unsigned s_hb[4][KP_HCOLS * KP_HSTRIDE / 2];
-    __shared__ int s_m[4][2];              // (m01, m10) of the four keypoints
-    __shared__ float s_ab[4][2];           // (cos, sin) of their angles
+    __shared__ __attribute__((aligned(8))) unsigned s_hb[KP_PER_WG][KP_HCOLS * KP_HSTRIDE / 2];
+    __shared__ int s_m[KP_PER_WG][2];              // (m01, m10) of the four keypoints
+    __shared__ float s_ab[KP_PER_WG][2];           // (cos, sin) of their angles
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int img, blk;
     if (!xcd_image_block(nb, n_img, img, blk)) return;
-    const int k = blk * 4 + wv;
+    const int k = blk * KP_PER_WG + wv;
     const int nkp = kp_count[img];
-    if (blk * 4 >= nkp) return;                               // workgroup-uniform: the grid is sized for the keypoint capacity
+    if (blk * KP_PER_WG >= nkp) return;                               // workgroup-uniform: the grid is sized for the keypoint capacity
     const bool active = k < nkp;
     const long long g = (long long)img * lay.kcap + (active ? k : 0);
     const unsigned p = kp_xy[g];
@@ -957,9 +963,9 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
         }
     }
     __syncthreads();
-    if (wv == 0 && lane < 4 && blk * 4 + lane < nkp) {
+    if (wv == 0 && lane < KP_PER_WG && blk * KP_PER_WG + lane < nkp) {
         const float angle = fast_atan2_deg((float)s_m[lane][0], (float)s_m[lane][1]);
-        kp_angle[(long long)img * lay.kcap + blk * 4 + lane] = angle;
+        kp_angle[(long long)img * lay.kcap + blk * KP_PER_WG + lane] = angle;
         const float ang = angle * (float)(3.141592653589793238462643383279502884 / 180.0);
         double sn, cs;
         det_sincos((double)ang, sn, cs);
@@ -1014,8 +1020,8 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(const uint8_t *__r
 
 void rpe_launch_angle(rpe_handle *h, int n_img)
 {
-    const int nb = (h->lay.kcap + 3) / 4;
-    hipLaunchKernelGGL(orient_describe_kernel, dim3(xcd_image_grid(nb, n_img)), dim3(256), 0, h->stream,
+    const int nb = (h->lay.kcap + KP_PER_WG - 1) / KP_PER_WG;
+    hipLaunchKernelGGL(orient_describe_kernel, dim3(xcd_image_grid(nb, n_img)), dim3(64 * KP_PER_WG), 0, h->stream,
                        h->d_pyr, h->d_kp_xy, h->d_kp_pt, h->d_kp_count, h->d_kp_angle, h->d_desc, h->lay, nb, n_img);
 }
 
