@@ -853,8 +853,10 @@ __global__ __launch_bounds__(64 * KP_PER_WG) void orient_describe_kernel(const u
     // contiguous bytes (three aligned ds_read_b64 instead of seven bank-conflicting ds_read_u16), and an MFMA lane, which
     // owns one column and 4 consecutive rows per register group, stores 8 bytes at a time
     __shared__ __attribute__((aligned(8))) unsigned s_hb[KP_PER_WG][KP_HCOLS * KP_HSTRIDE / 2];
-    __shared__ int s_m[KP_PER_WG][2];              // (m01, m10) of the four keypoints
+#if KP_PER_WG > 1
+    __shared__ int s_m[KP_PER_WG][2];              // (m01, m10) of the workgroup's keypoints
     __shared__ float s_ab[KP_PER_WG][2];           // (cos, sin) of their angles
+#endif
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int img, blk;
     if (!xcd_image_block(nb, n_img, img, blk)) return;
@@ -883,6 +885,7 @@ __global__ __launch_bounds__(64 * KP_PER_WG) void orient_describe_kernel(const u
         }
     }
     __syncthreads();
+    int km01 = 0, km10 = 0;
     if (active) {
         // ---- orb.cpp ICAngles: integer moments over the disc, reduced with wave shuffles
         // integer sums, so any summation order gives the oracle's moments: 4 disc pixels per packed-u8 dot product
@@ -912,7 +915,11 @@ __global__ __launch_bounds__(64 * KP_PER_WG) void orient_describe_kernel(const u
         m01 = wave_sum(m01);
         // fastAtan2 and the deterministic sincos are ~100 vector instructions on wave-uniform values: the four keypoints
         // of the workgroup get them from four LANES of wave 0 after the barrier below instead of from four waves
+#if KP_PER_WG > 1
         if (lane == 0) { s_m[wv][0] = m01; s_m[wv][1] = m10; }
+#else
+        km01 = m01; km10 = m10;
+#endif
         // ---- horizontal pass on the matrix cores: hbuf column j <-> x = x0 - 19 + j (40 per row; the descriptor reaches
         // |dx| <= 18).  H[45 x 40] = P[45 x 48 raw bytes] . T[48 x 40] with the banded tap matrix T[k][j] = tap[k - off0 - j]
         // (tap = cvRound(256 g) = 18,34,49,55,49,34,18): 2 x 2 output tiles x 2 K-steps of v_mfma_i32_32x32x32_i8, exact
@@ -963,6 +970,7 @@ __global__ __launch_bounds__(64 * KP_PER_WG) void orient_describe_kernel(const u
         }
     }
     __syncthreads();
+#if KP_PER_WG > 1
     if (wv == 0 && lane < KP_PER_WG && blk * KP_PER_WG + lane < nkp) {
         const float angle = fast_atan2_deg((float)s_m[lane][0], (float)s_m[lane][1]);
         kp_angle[(long long)img * lay.kcap + blk * KP_PER_WG + lane] = angle;
@@ -974,6 +982,19 @@ __global__ __launch_bounds__(64 * KP_PER_WG) void orient_describe_kernel(const u
     __syncthreads();
     if (!active) return;
     const float a = s_ab[wv][0], b = s_ab[wv][1];
+#else
+    // one keypoint per workgroup: the wave evaluates its own angle (uniform values), no exchange and no barrier
+    if (!active) return;
+    float a, b;
+    {
+        const float angle = fast_atan2_deg((float)km01, (float)km10);
+        if (lane == 0) kp_angle[g] = angle;
+        const float ang = angle * (float)(3.141592653589793238462643383279502884 / 180.0);
+        double sn, cs;
+        det_sincos((double)ang, sn, cs);
+        a = (float)cs; b = (float)sn;
+    }
+#endif
     // ---- orb.cpp computeOrbDescriptors: lane = 4 consecutive bit tests, vertical pass at the samples
     const uint8_t *hbytes = (const uint8_t *)hb;
     const float2 pt = kp_pt[g];
