@@ -101,18 +101,18 @@ __device__ __forceinline__ bool xcd_image_block(int nb, int n_img, int &img, int
 static inline unsigned xcd_image_grid(int nb, int n_img) { return (unsigned)(8 * ((n_img + 7) / 8) * nb); }
 
 // ---------------------------------------------------------------- pyramid
-// Workgroup = 128x64 destination tile of level l.  The source footprint in level l-1
-// (<= 74 rows x 152 bytes, bounds derived arithmetically so the loads do not depend on
-// the coefficient tables; checked on the host) is staged in LDS with aligned dword loads, all of
-// them in flight before the first LDS store -- ~13 KB per workgroup.
+// Workgroup = 128 x PYR_TH destination tile of level l.  The source footprint in level l-1
+// (<= PYR_ROWS rows x 152 bytes, bounds derived arithmetically so the loads do not depend on
+// the coefficient tables; checked on the host) is staged in LDS with aligned 16-byte loads, all of
+// them in flight before the first LDS store -- 6.9 KB per workgroup at PYR_TH = 32.
 // One lane = 4 destination columns x 8 consecutive destination rows.  The bilinear chain is separable in exact
 // integer arithmetic: h(src row, dst col) = a0 p[o] + a1 p[o+1] (16 bits), out = (b0 h(top) + b1 h(bottom) + 2^15) >> 16.
 // Reading p[o+1] and the row below unclamped is exact: the coefficient tables give weight 0 wherever OpenCV clamps
 // (last source column / row).  The row loop is described where it stands.
 #define PYR_TW 128
-#define PYR_ROWS 74
 #define PYR_DW 44                    // 176 B per window row = 11 x 16-B loads (origin aligned down to 16 B)
-#define PYR_THREADS 128               // two waves per 128x64 tile: 12 workgroups (156 KB of windows) per CU instead of 8 x four waves
+// PYR_TH (tile height), PYR_ROWS (window rows) and PYR_THREADS live in rpe_internal.h: the host builds the tile table from them
+#define PYR_NRG (PYR_THREADS / 32)    // row groups of 8 rows side by side in a workgroup; a lane takes groups ty8 and ty8 + PYR_NRG
 __global__ __launch_bounds__(PYR_THREADS) void pyr_resize_kernel(uint8_t *pyr, RpeDeviceLayout lay, const int *__restrict__ coef,
                                                                   const RpePyrTile *__restrict__ ptiles, int ntiles, int l)
 {
@@ -136,14 +136,15 @@ __global__ __launch_bounds__(PYR_THREADS) void pyr_resize_kernel(uint8_t *pyr, R
     // The kernel lives on how many tile windows a CU keeps in flight (r02 diagnostic builds: loads + LDS alone 1.12 ms, rows +
     // stores alone 1.26 ms, together 1.92 ms -- the phases of a workgroup overlap only through OTHER workgroups, and FAST
     // run beside it on a second stream gained nothing: wave slots are the contended resource).  A lane therefore takes 4
-    // columns x TWO row groups of 8 rows: half the waves per window, 12 windows per CU, and the column constants serve 16 rows.
-    const int tx = tid & 31, ty8 = tid >> 5;               // row groups ty8 and ty8 + 4
+    // columns x TWO row groups of 8 rows (half the waves per window, the column constants serve 16 rows), and the tile is
+    // only PYR_TH = 32 rows high: one wave per tile, 23 independent windows per CU.
+    const int tx = tid & 31, ty8 = tid >> 5;               // row groups ty8 and ty8 + PYR_NRG
     const int x4 = x0 + 4 * tx;
     // coefficient loads go out first, in the shadow of the window loads
     const int4 cv = *(const int4 *)(cxp + x4);
     int4 rq[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) rq[k] = *(const int4 *)(cyp + y0 + (ty8 + 4 * (k >> 1)) * 8 + 4 * (k & 1));
+    for (int k = 0; k < 4; ++k) rq[k] = *(const int4 *)(cyp + y0 + (ty8 + PYR_NRG * (k >> 1)) * 8 + 4 * (k & 1));
     {   // all window loads (16 B per lane) in flight before the first LDS store (one HBM round trip per tile):
         // chunk i = tid + 128 q of the 74 x 11 chunks of the window, row i / 11, 16-B column i % 11
         constexpr int NQ = PYR_DW / 4, NCHUNK = PYR_ROWS * NQ, NLD = (NCHUNK + PYR_THREADS - 1) / PYR_THREADS;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(PYR_THREADS) void pyr_resize_kernel(uint8_t *pyr, R
     const unsigned colmask = x4 + 3 < D.w ? 0xFFFFFFFFu : (x4 >= D.w ? 0u : (0xFFFFFFFFu >> (8 * (x4 + 4 - D.w))));   // bytes past D.w stay 0
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        const int yb = y0 + (ty8 + 4 * half) * 8;
+        const int yb = y0 + (ty8 + PYR_NRG * half) * 8;
         uint8_t *dstp = base + D.off + __umul24((unsigned)yb, (unsigned)D.pitch) + x4;
         const int nrows = min(8, D.h - yb);
 #pragma unroll

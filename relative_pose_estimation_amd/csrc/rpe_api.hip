@@ -156,13 +156,13 @@ static int build_tables(rpe_handle *h)
         lin_coeffs(S.w, D.w, xo, xa);
         lin_coeffs(S.h, D.h, yo, ya);
     }
-    // resize tiles (128x64 destination pixels) with the origin of their source window, levels 1..11
+    // resize tiles (128 x PYR_TH destination pixels) with the origin of their source window, levels 1..11
     {
         std::vector<RpePyrTile> pt;
         for (int l = 1; l < RPE_NLEVELS; ++l) {
             const RpeLevel &S = L.lv[l - 1], &D = L.lv[l];
             h->pyr_tile_off[l] = (int)pt.size();
-            for (int y0 = 0; y0 < D.h; y0 += 64)
+            for (int y0 = 0; y0 < D.h; y0 += PYR_TH)
                 for (int x0 = 0; x0 < D.pitch; x0 += 128)
                     pt.push_back({(short)x0, (short)y0, (short)(((int)(((long long)x0 * S.w) / D.w)) & ~15), (short)(((long long)y0 * S.h) / D.h)});
             h->pyr_tile_cnt[l] = (int)pt.size() - h->pyr_tile_off[l];
@@ -170,7 +170,7 @@ static int build_tables(rpe_handle *h)
         DM(h, h->d_pyr_tiles, pt.size() ? pt.size() : 1);
         if (!pt.empty()) HIPCHK(h, hipMemcpy(h->d_pyr_tiles, pt.data(), pt.size() * sizeof(RpePyrTile), hipMemcpyHostToDevice));
     }
-    // the resize kernel stages a fixed 74-row x 176-byte source footprint per 128x64 tile (origin 16-B aligned),
+    // the resize kernel stages a fixed PYR_ROWS-row x 176-byte source footprint per 128 x PYR_TH tile (origin 16-B aligned),
     // anchored at floor(scale * tile origin); verify the tables fit it for every tile
     for (int l = 1; l < RPE_NLEVELS; ++l) {
         const RpeLevel &S = L.lv[l - 1], &D = L.lv[l];
@@ -180,10 +180,10 @@ static int build_tables(rpe_handle *h)
             int hi = xo[xl] + 1 < S.w ? xo[xl] + 1 : S.w - 1;
             if (xo[x0] < a0 || hi - a0 >= 176) { h->err = "pyramid footprint bound violated (x)"; return RPE_ERR_INVALID; }
         }
-        for (int y0 = 0; y0 < D.h; y0 += 64) {
-            int s0 = (int)(((long long)y0 * S.h) / D.h), yl = y0 + 63 < D.h ? y0 + 63 : D.h - 1;
+        for (int y0 = 0; y0 < D.h; y0 += PYR_TH) {
+            int s0 = (int)(((long long)y0 * S.h) / D.h), yl = y0 + PYR_TH - 1 < D.h ? y0 + PYR_TH - 1 : D.h - 1;
             int hi = yo[yl] + 1 < S.h ? yo[yl] + 1 : S.h - 1;
-            if (yo[y0] < s0 || hi - s0 >= 74) { h->err = "pyramid footprint bound violated (y)"; return RPE_ERR_INVALID; }
+            if (yo[y0] < s0 || hi - s0 >= PYR_ROWS) { h->err = "pyramid footprint bound violated (y)"; return RPE_ERR_INVALID; }
         }
     }
     // device form: (offset, weight) packed into one dword per destination column / row (offset < 65536, weight <= 256).

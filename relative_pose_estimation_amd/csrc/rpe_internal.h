@@ -76,8 +76,16 @@ RPE_WAVE_SCAN(wave_inclusive_min, RPE_OP_MIN, 0x7FFFFFFF)
 __device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_inclusive_sum(v), 63); }
 
 struct RpeTile { short level, tx, ty, pad; };
-// 128x64 destination tile of the resize kernel: destination origin and origin of its source window in the level below
+// 128 x PYR_TH destination tile of the resize kernel: destination origin and origin of its source window in the level below
 struct RpePyrTile { short x0, y0, a0, sy0; };
+// destination tile 128 x PYR_TH; a lane computes 4 columns x 2 groups of 8 rows.  32 rows = ONE wave per tile and 23 tile
+// windows (6.9 KB each) per CU: 1.89 -> 1.68 ms against 64 rows / two waves / 12 windows (the phases of a tile overlap
+// only through other workgroups, so many small independent ones beat few large ones)
+#ifndef PYR_TH
+#define PYR_TH 32
+#endif
+#define PYR_THREADS (PYR_TH * 2)     // 32 column groups x PYR_TH / 16 row-group pairs
+#define PYR_ROWS (PYR_TH == 64 ? 74 : 39)   // source rows staged per tile (checked against the tables at create time)
 
 // per-pair RANSAC state in HBM
 struct RpeRansacState {
