@@ -265,20 +265,25 @@ typedef short short2_t __attribute__((ext_vector_type(2)));
 static constexpr int CIRC_DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
 static constexpr int CIRC_DY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
 
-#define FS_ROWS 66          // score rows / columns region (y0-1 .. y0+64)
+#define FS_ROWS (FAST_TH + 2)        // score rows (y0-1 .. y0+FAST_TH)
+#define FAST_PROWS (FAST_TH + 8)     // pixel rows (y0-4 .. y0+FAST_TH+3)
+#define FAST_THREADS (FAST_TH * 4)
+#define FAST_NRP (FAST_THREADS / 18)  // rows of the 18-dword tile row that one pass of the lanes covers (14 or 7)
+#define FAST_LANES (FAST_NRP * 18)
 // Output: one compact list per tile of the keypoints that survive NMS and the border filter, packed
 // score << 24 | y << 12 | x (level coordinates), plus the per-(image, level) score histogram.  A strict 3x3
 // maximum cannot have an 8-neighbour that is one too, so a 64x64 tile holds at most 32*32 = 1024 of them:
 // RPE_FAST_TILE_CAP is never exceeded and nothing is ever dropped here.  ~0.5 % of the pixels survive, so
 // the lists replace a dense NMS map (1.6 MB written + re-read per VGA image) by ~100 bytes per tile; list
 // order inside a tile depends on wave timing, which nothing downstream reads (select ranks by (y, x)).
-__global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict__ pyr, unsigned *__restrict__ tile_list,
+__global__ __launch_bounds__(FAST_THREADS) void fast_nms_kernel(const uint8_t *__restrict__ pyr, unsigned *__restrict__ tile_list,
                                                         int *__restrict__ tile_cnt, unsigned *__restrict__ hist, RpeDeviceLayout lay,
                                                         const RpeTile *__restrict__ tiles, int ntiles)
 {
     // 19.5 KB of LDS per workgroup = 8 workgroups (32 waves) per CU: the pixel tile is dead after phase 2, so the keypoint
     // list and the histogram of phase 3 live in its place (4096 + 1024 <= 5184 bytes); at 24.5 KB only 6 workgroups fit
-    __shared__ __attribute__((aligned(16))) unsigned s_in[72 * 18];              // pixels  y0-4 .. y0+67, x0-4 .. x0+67
+    constexpr int S_IN_DW = FAST_PROWS * 18 > RPE_FAST_TILE_CAP + 256 ? FAST_PROWS * 18 : RPE_FAST_TILE_CAP + 256;
+    __shared__ __attribute__((aligned(16))) unsigned s_in[S_IN_DW];                // pixels  y0-4 .. y0+FAST_TH+3, x0-4 .. x0+67 (sized for the phase-3 aliases too)
     __shared__ __attribute__((aligned(16))) unsigned s_sc[FS_ROWS * 18];   // scores  y0-1 .. y0+64, x0-4 .. x0+67
     unsigned *s_out = s_in;                                               // phase 3: the tile's keypoint list [1024]
     unsigned *s_hist = s_in + RPE_FAST_TILE_CAP;                          // phase 3: score histogram [256]
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
     const long long tslot = (long long)blockIdx.y * ntiles + ti;
     // tiles that cannot contain a keypoint after the border filter (the host table lists none): empty list
     const bool live = w > 2 * RPE_EDGE && hgt > 2 * RPE_EDGE && x0 < w - RPE_EDGE && x0 + 64 > RPE_EDGE &&
-                      y0 < hgt - RPE_EDGE && y0 + 64 > RPE_EDGE;
+                      y0 < hgt - RPE_EDGE && y0 + FAST_TH > RPE_EDGE;
     if (!live) {
         if (tid == 0) tile_cnt[tslot] = 0;
         return;
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
         unsigned stage[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-            const int r = min(lr + 14 * q, 71);
+            const int r = min(lr + FAST_NRP * q, FAST_PROWS - 1);
             const int y = min(max(y0 - 4 + r, 0), hgt - 1);
             stage[q] = *(const unsigned *)(src + (__umul24((unsigned)y, (unsigned)pitch) + (unsigned)lx));
         }
@@ -316,12 +321,12 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
 #pragma unroll
         for (int q = 0; q < 6; ++q) asm volatile("" : "+v"(stage[q]));
 #pragma unroll
-        for (int q = 0; q < 6; ++q) { const int r = lr + 14 * q; if (tid < 252 && r < 72) s_in[r * 18 + lc] = stage[q]; }
+        for (int q = 0; q < 6; ++q) { const int r = lr + FAST_NRP * q; if (tid < FAST_LANES && r < FAST_PROWS) s_in[r * 18 + lc] = stage[q]; }
     }
     {   // zero the score tile with 16-B LDS stores
         uint4 *z1 = (uint4 *)s_sc;
         const uint4 z = make_uint4(0, 0, 0, 0);
-        for (int i = tid; i < FS_ROWS * 18 / 4; i += 256) z1[i] = z;
+        for (int i = tid; i < FS_ROWS * 18 / 4; i += FAST_THREADS) z1[i] = z;
     }
     __syncthreads();
     // ---- phase 1 (packed 16-bit SWAR: even / odd pixels of the dword group in one VGPR each)
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
     const unsigned T1 = (unsigned)(thr + 1) * 0x00010001u, T0 = (unsigned)thr * 0x00010001u;
     const int c = tid % 18, r0 = tid / 18;
     unsigned cand_bits = 0;
-    if (tid < 252) {
+    if (tid < FAST_LANES) {
         const int cl = max(c - 1, 0), cr = min(c + 1, 17);
         const int pxb = x0 - 4 + 4 * c;
         const int xlo = max(x0 - 1, RPE_EDGE - 1), xhi = min(x0 + 64, w - RPE_EDGE);   // valid px range (inclusive)
@@ -345,12 +350,12 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
         const unsigned *pC = s_in + (r0 + 3) * 18 + c, *pL = s_in + (r0 + 3) * 18 + cl, *pR = s_in + (r0 + 3) * 18 + cr;
 #pragma unroll
         for (int it = 0; it < 5; ++it) {
-            const int ry = r0 + 14 * it;
+            const int ry = r0 + FAST_NRP * it;
             const int py = y0 - 1 + ry;
             if (vmask == 0 || ry >= FS_ROWS || py < RPE_EDGE - 1 || py >= hgt - RPE_EDGE + 1) continue;
             // input row of this score row = ry + 3; the three column pointers are per-lane constants, the rows compile-time
             // offsets from them (ds_read immediate offsets instead of six address instructions per row)
-            const int ro = 14 * 18 * it;
+            const int ro = FAST_NRP * 18 * it;
             const unsigned cdw = pC[ro], ldw = pL[ro], rdw = pR[ro];
             const unsigned upl = pL[ro - 36], upc = pC[ro - 36], upr = pR[ro - 36];
             const unsigned dnl = pL[ro + 36], dnc = pC[ro + 36], dnr = pR[ro + 36];
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
             while (bits) {
                 const int bpos = __ffs((int)bits) - 1;
                 bits &= bits - 1;
-                s_cand[pos++] = (unsigned short)(((r0 + 14 * (bpos & 7)) << 7) | (4 * c + (bpos >> 3)));
+                s_cand[pos++] = (unsigned short)(((r0 + FAST_NRP * (bpos & 7)) << 7) | (4 * c + (bpos >> 3)));
             }
         }
     }
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
     // ---- phase 2
     const int ncand = s_ncand;
     const uint8_t *sb = (const uint8_t *)s_in;
-    for (int i = tid; i < ncand; i += 256) {
+    for (int i = tid; i < ncand; i += FAST_THREADS) {
         const int cc = s_cand[i];
         const int bx = cc & 127, ry = cc >> 7;
         const uint8_t *p = sb + (ry + 3) * 72 + bx;
@@ -436,10 +441,10 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
     // ---- phase 3: NMS + border filter + histogram over the candidate list (only pixels that went through
     // phase 2 can hold a score); survivors are appended to the tile's list, one LDS atomic per wave and round.
     // The pixel tile is dead now (the barrier above ended phase 2): its LDS holds the list and the histogram.
-    s_hist[tid] = 0;
+    for (int i = tid; i < 256; i += FAST_THREADS) s_hist[i] = 0;
     __syncthreads();
     const uint8_t *sc = (const uint8_t *)s_sc;
-    for (int i0 = 0; i0 < ncand; i0 += 256) {                  // block-uniform trip count: the ballot sees whole waves
+    for (int i0 = 0; i0 < ncand; i0 += FAST_THREADS) {                  // block-uniform trip count: the ballot sees whole waves
         const int i = i0 + tid;
         bool keep = false;
         unsigned ent = 0;
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
             // branch-free: the eight neighbour reads go out together (as a short-circuit chain they were nine dependent LDS
             // round trips with an exec-mask save / restore each); reads of halo candidates past the score tile land in
             // other LDS arrays of this kernel and are discarded by `inside`
-            const bool inside = (unsigned)(bx - 4) < 64u & (unsigned)(ry - 1) < 64u &                 // halo pixels are not outputs
+            const bool inside = (unsigned)(bx - 4) < 64u & (unsigned)(ry - 1) < (unsigned)FAST_TH &                 // halo pixels are not outputs
                                 (unsigned)(px - RPE_EDGE) < (unsigned)(w - 2 * RPE_EDGE) & (unsigned)(py - RPE_EDGE) < (unsigned)(hgt - 2 * RPE_EDGE);
             const uint8_t *q = sc + ry * 72 + bx;
             const int v = q[0];
@@ -472,10 +477,12 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *__restrict
     __syncthreads();
     const int nout = s_nout;                                   // <= RPE_FAST_TILE_CAP by the NMS argument above
     unsigned *dst = tile_list + tslot * RPE_FAST_TILE_CAP;
-    for (int i = tid; i < nout; i += 256) dst[i] = s_out[i];
+    for (int i = tid; i < nout; i += FAST_THREADS) dst[i] = s_out[i];
     if (tid == 0) tile_cnt[tslot] = nout;
-    const unsigned hc = s_hist[tid];
-    if (hc) atomicAdd(&hist[((long long)blockIdx.y * RPE_NLEVELS + t.level) * 256 + tid], hc);
+    for (int i = tid; i < 256; i += FAST_THREADS) {
+        const unsigned hc = s_hist[i];
+        if (hc) atomicAdd(&hist[((long long)blockIdx.y * RPE_NLEVELS + t.level) * 256 + i], hc);
+    }
 }
 
 void rpe_launch_fast(rpe_handle *h, int n_img)
@@ -483,7 +490,7 @@ void rpe_launch_fast(rpe_handle *h, int n_img)
     hipMemsetAsync(h->d_hist, 0, sizeof(unsigned) * 256 * RPE_NLEVELS * (size_t)n_img, h->stream);
     // tiles cover the border-filtered region only
     if (h->n_tiles_fast == 0) return;
-    hipLaunchKernelGGL(fast_nms_kernel, dim3((h->n_tiles_fast + 7) / 8 * 8, n_img), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL(fast_nms_kernel, dim3((h->n_tiles_fast + 7) / 8 * 8, n_img), dim3(FAST_THREADS), 0, h->stream,
                        h->d_pyr, h->d_tile_list, h->d_tile_cnt, h->d_hist, h->lay, h->d_tiles_fast, h->n_tiles_fast);
 }
 

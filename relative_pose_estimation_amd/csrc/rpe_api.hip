@@ -138,7 +138,7 @@ static int build_tables(rpe_handle *h)
         h->lay.lv[l].tile0 = (int)fast.size();
         if (v.w > 2 * RPE_EDGE && v.h > 2 * RPE_EDGE)
             // keypoints survive the border filter on [31, w-31) x [31, h-31) only; x origin dword aligned
-            for (int y = RPE_EDGE; y < v.h - RPE_EDGE; y += 64)
+            for (int y = RPE_EDGE; y < v.h - RPE_EDGE; y += FAST_TH)
                 for (int x = RPE_EDGE & ~3; x < v.w - RPE_EDGE; x += 64) fast.push_back({(short)l, (short)x, (short)y, 0});
         h->lay.lv[l].ntile = (int)fast.size() - h->lay.lv[l].tile0;
     }

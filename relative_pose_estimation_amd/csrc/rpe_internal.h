@@ -14,7 +14,12 @@
 #define RPE_RANSAC_MAXCHUNK 512 // largest number of iterations evaluated per launch group (8 waves per pair)
 #define RPE_MAX_MODELS 10
 #define RPE_RESULT_BYTES 108     // per pair: R 72 + t 24 + inliers 4 + status 4 + n_matches 4
-#define RPE_FAST_TILE_CAP 1024 // entries of one 64x64 FAST tile list = the most strict 3x3 maxima a tile can hold
+// FAST tile = 64 x FAST_TH output pixels, FAST_TH * 4 threads.  Unlike the resize kernel (latency bound: smaller tiles
+// won), FAST is bound by instruction issue and 32-row tiles with two waves only add halo work: 4.43 -> 4.79 ms.
+#ifndef FAST_TH
+#define FAST_TH 64
+#endif
+#define RPE_FAST_TILE_CAP (FAST_TH * 16) // entries of one FAST tile list = the most strict 3x3 maxima a 64 x FAST_TH tile can hold
 
 // ---- HBM layout of one image's pyramid-shaped buffers ---------------------
 // Level l is stored with row pitch align16(w_l) at byte offset off[l] (256-B
