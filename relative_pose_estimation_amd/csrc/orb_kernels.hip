@@ -109,10 +109,11 @@ static inline unsigned xcd_image_grid(int nb, int n_img) { return (unsigned)(8 *
 // integer arithmetic: h(src row, dst col) = a0 p[o] + a1 p[o+1] (16 bits), out = (b0 h(top) + b1 h(bottom) + 2^15) >> 16.
 // Reading p[o+1] and the row below unclamped is exact: the coefficient tables give weight 0 wherever OpenCV clamps
 // (last source column / row).  The row loop is described where it stands.
-#define PYR_TW 128
-#define PYR_DW 44                    // 176 B per window row = 11 x 16-B loads (origin aligned down to 16 B)
-// PYR_TH (tile height), PYR_ROWS (window rows) and PYR_THREADS live in rpe_internal.h: the host builds the tile table from them
-#define PYR_NRG (PYR_THREADS / 32)    // row groups of 8 rows side by side in a workgroup; a lane takes groups ty8 and ty8 + PYR_NRG
+// PYR_TW / PYR_TH (tile size), PYR_DW / PYR_ROWS (window size) and PYR_THREADS live in rpe_internal.h: the host builds the
+// tile table from them
+#define PYR_NCG (PYR_TW / 4)                    // column groups of 4 pixels per tile row
+#define PYR_NRG (PYR_THREADS / PYR_NCG)         // row groups of 8 rows side by side in a workgroup
+#define PYR_RGPL ((PYR_TH / 8) / PYR_NRG)       // row groups per lane: ty8, ty8 + PYR_NRG, ...
 __global__ __launch_bounds__(PYR_THREADS) void pyr_resize_kernel(uint8_t *pyr, RpeDeviceLayout lay, const int *__restrict__ coef,
                                                                   const RpePyrTile *__restrict__ ptiles, int ntiles, int l)
 {
@@ -138,13 +139,13 @@ __global__ __launch_bounds__(PYR_THREADS) void pyr_resize_kernel(uint8_t *pyr, R
     // run beside it on a second stream gained nothing: wave slots are the contended resource).  A lane therefore takes 4
     // columns x TWO row groups of 8 rows (half the waves per window, the column constants serve 16 rows), and the tile is
     // only PYR_TH = 32 rows high: one wave per tile, 23 independent windows per CU.
-    const int tx = tid & 31, ty8 = tid >> 5;               // row groups ty8 and ty8 + PYR_NRG
+    const int tx = tid % PYR_NCG, ty8 = tid / PYR_NCG;     // row groups ty8, ty8 + PYR_NRG, ...
     const int x4 = x0 + 4 * tx;
     // coefficient loads go out first, in the shadow of the window loads
     const int4 cv = *(const int4 *)(cxp + x4);
-    int4 rq[4];
+    int4 rq[2 * PYR_RGPL];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) rq[k] = *(const int4 *)(cyp + y0 + (ty8 + PYR_NRG * (k >> 1)) * 8 + 4 * (k & 1));
+    for (int k = 0; k < 2 * PYR_RGPL; ++k) rq[k] = *(const int4 *)(cyp + y0 + (ty8 + PYR_NRG * (k >> 1)) * 8 + 4 * (k & 1));
     {   // all window loads (16 B per lane) in flight before the first LDS store (one HBM round trip per tile):
         // chunk i = tid + 128 q of the 74 x 11 chunks of the window, row i / 11, 16-B column i % 11
         constexpr int NQ = PYR_DW / 4, NCHUNK = PYR_ROWS * NQ, NLD = (NCHUNK + PYR_THREADS - 1) / PYR_THREADS;
@@ -183,14 +184,17 @@ __global__ __launch_bounds__(PYR_THREADS) void pyr_resize_kernel(uint8_t *pyr, R
     // weight << 16).  Materialised here: rematerialised inside the row loop, every row's first use of a table register sits
     // behind an s_waitcnt vmcnt(0) -- which on gfx9 also waits for the previous row's global STORE (rows serialised on HBM
     // write latency)
-    unsigned rc[16];
+    unsigned rc[8 * PYR_RGPL];
     {
-        const int rv[16] = {rq[0].x, rq[0].y, rq[0].z, rq[0].w, rq[1].x, rq[1].y, rq[1].z, rq[1].w,
-                            rq[2].x, rq[2].y, rq[2].z, rq[2].w, rq[3].x, rq[3].y, rq[3].z, rq[3].w};
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            rc[rr] = (__umul24((unsigned)((rv[rr] & 0xFFFF) - sy0), PYR_DW) + (unsigned)(bcol >> 2)) | ((unsigned)rv[rr] & 0xFFFF0000u);
-            asm volatile("" : "+v"(rc[rr]));
+        for (int k = 0; k < 2 * PYR_RGPL; ++k) {
+            const int rv4[4] = {rq[k].x, rq[k].y, rq[k].z, rq[k].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int rr = 4 * k + e;
+                rc[rr] = (__umul24((unsigned)((rv4[e] & 0xFFFF) - sy0), PYR_DW) + (unsigned)(bcol >> 2)) | ((unsigned)rv4[e] & 0xFFFF0000u);
+                asm volatile("" : "+v"(rc[rr]));
+            }
         }
     }
     __syncthreads();
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(PYR_THREADS) void pyr_resize_kernel(uint8_t *pyr, R
     const unsigned sh = (unsigned)bcol & 3u;
     const unsigned colmask = x4 + 3 < D.w ? 0xFFFFFFFFu : (x4 >= D.w ? 0u : (0xFFFFFFFFu >> (8 * (x4 + 4 - D.w))));   // bytes past D.w stay 0
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < PYR_RGPL; ++half) {
         const int yb = y0 + (ty8 + PYR_NRG * half) * 8;
         uint8_t *dstp = base + D.off + __umul24((unsigned)yb, (unsigned)D.pitch) + x4;
         const int nrows = min(8, D.h - yb);

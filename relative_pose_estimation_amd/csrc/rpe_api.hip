@@ -163,7 +163,7 @@ static int build_tables(rpe_handle *h)
             const RpeLevel &S = L.lv[l - 1], &D = L.lv[l];
             h->pyr_tile_off[l] = (int)pt.size();
             for (int y0 = 0; y0 < D.h; y0 += PYR_TH)
-                for (int x0 = 0; x0 < D.pitch; x0 += 128)
+                for (int x0 = 0; x0 < D.pitch; x0 += PYR_TW)
                     pt.push_back({(short)x0, (short)y0, (short)(((int)(((long long)x0 * S.w) / D.w)) & ~15), (short)(((long long)y0 * S.h) / D.h)});
             h->pyr_tile_cnt[l] = (int)pt.size() - h->pyr_tile_off[l];
         }
@@ -175,10 +175,10 @@ static int build_tables(rpe_handle *h)
     for (int l = 1; l < RPE_NLEVELS; ++l) {
         const RpeLevel &S = L.lv[l - 1], &D = L.lv[l];
         const int *xo = coef.data() + D.coef_off, *yo = xo + 2 * D.w;
-        for (int x0 = 0; x0 < D.w; x0 += 128) {
-            int a0 = ((int)(((long long)x0 * S.w) / D.w)) & ~15, xl = x0 + 127 < D.w ? x0 + 127 : D.w - 1;
+        for (int x0 = 0; x0 < D.w; x0 += PYR_TW) {
+            int a0 = ((int)(((long long)x0 * S.w) / D.w)) & ~15, xl = x0 + PYR_TW - 1 < D.w ? x0 + PYR_TW - 1 : D.w - 1;
             int hi = xo[xl] + 1 < S.w ? xo[xl] + 1 : S.w - 1;
-            if (xo[x0] < a0 || hi - a0 >= 176) { h->err = "pyramid footprint bound violated (x)"; return RPE_ERR_INVALID; }
+            if (xo[x0] < a0 || hi - a0 >= PYR_DW * 4) { h->err = "pyramid footprint bound violated (x)"; return RPE_ERR_INVALID; }
         }
         for (int y0 = 0; y0 < D.h; y0 += PYR_TH) {
             int s0 = (int)(((long long)y0 * S.h) / D.h), yl = y0 + PYR_TH - 1 < D.h ? y0 + PYR_TH - 1 : D.h - 1;

@@ -89,7 +89,13 @@ struct RpePyrTile { short x0, y0, a0, sy0; };
 #ifndef PYR_TH
 #define PYR_TH 32
 #endif
+#ifndef PYR_TW
+#define PYR_TW 128                   // destination tile width (64-wide tiles, also one wave each, measured 1.67 -> 1.82 ms)
+#endif
+#define PYR_DW (PYR_TW == 128 ? 44 : 24)    // window row in dwords: 176 B = 11 x 16-B loads (origin aligned down to 16 B), 96 B for 64-wide tiles
+#ifndef PYR_THREADS
 #define PYR_THREADS (PYR_TH * 2)     // 32 column groups x PYR_TH / 16 row-group pairs
+#endif
 #define PYR_ROWS (PYR_TH == 64 ? 74 : 39)   // source rows staged per tile (checked against the tables at create time)
 
 // per-pair RANSAC state in HBM
