@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void match_hamming_kernel(const uint8_t *__res
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 #define MM_NT 512
+#define MM_PF 4                      // query tiles fetched ahead of the one being multiplied
 
 __device__ __forceinline__ v4i_t expand16(unsigned b)
 {
@@ -181,6 +182,13 @@ __global__ __launch_bounds__(MM_NT) void match_hamming_mfma_kernel(const uint8_t
     for (int i = tid; i < n1; i += MM_NT) s_best[i] = 0xFFFFFFFFu;
     if (tid == 0) s_valid = 0;
     const unsigned *q32 = (const unsigned *)(desc + (long long)img1 * kcap * 32);      // 8 dwords per query descriptor
+    // |q| + 512 of every query, once (the four passes over the query tiles all need them); kept in the free part of the
+    // first 32 KB (kcap <= 8064 entries)
+    unsigned short *s_qpop = (unsigned short *)(s_dyn + 2 * 8 * 64 + 16);
+    for (int i = tid; i < n1; i += MM_NT) {
+        const uint4 a = ((const uint4 *)q32)[2 * i], b = ((const uint4 *)q32)[2 * i + 1];
+        s_qpop[i] = (unsigned short)(512u + __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w));
+    }
     const uint4 *d2 = (const uint4 *)(desc + (long long)img2 * kcap * 32);
     const int ntq = (n1 + 31) >> 5, ntt = (n2 + 31) >> 5;
     const int h = lane >> 5, col = lane & 31;
@@ -202,44 +210,54 @@ __global__ __launch_bounds__(MM_NT) void match_hamming_mfma_kernel(const uint8_t
             for (int sK = 0; sK < 8; ++sK) { bop[sK] = expand16((tw[sK] >> (16 * h)) & 0xFFFFu); tpop += __popc(tw[sK]); }
         }
         unsigned best_key = 0xFFFFFFFFu;
-        // prologue: query tile 0 into buffer 0
-        unsigned nxt = 0, nxt_pop = 0;
-        auto fetch = [&](int qt) {
+        // The raw query words are fetched MM_PF tiles ahead into a register ring: with a one-tile lookahead every step of
+        // the loop waited for an L2 round trip (diagnostic build: the loop without its MFMAs took 0.17 of the kernel's
+        // 0.35 ms -- 128 steps of 1.3 us).  The loop is unrolled by MM_PF so that the ring is indexed statically.
+        unsigned ring[MM_PF];
+        auto fetch = [&](int qt) -> unsigned {
             const int q = qt * 32 + xrow;
-            nxt = q < n1 ? q32[(long long)q * 8 + xs] : 0u;
-            if (tid < 32) {                                    // |q| of row tid for the packed key words
+            return (qt < ntq && q < n1) ? q32[(long long)q * 8 + xs] : 0u;
+        };
+        auto stage = [&](int qt, int buf, unsigned raw) {
+            s_a[(buf * 8 + xs) * 64 + xl] = expand16((raw >> (16 * xh)) & 0xFFFFu);
+            if (tid < 32) {
                 const int qq = qt * 32 + tid;
-                nxt_pop = 0x7000u;                             // rows past n1: a key no real distance can beat
-                if (qq < n1) {
-                    const uint4 a = ((const uint4 *)q32)[2 * qq], b = ((const uint4 *)q32)[2 * qq + 1];
-                    nxt_pop = 512u + __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
-                }
+                const unsigned pk = qq < n1 ? (unsigned)s_qpop[qq] : 0x7000u;      // rows past n1: a key no real distance can beat
+                s_qpk[buf * 32 + tid] = (pk << 16) | (unsigned)qq;
             }
         };
-        auto stage = [&](int qt, int buf) {
-            s_a[(buf * 8 + xs) * 64 + xl] = expand16((nxt >> (16 * xh)) & 0xFFFFu);
-            if (tid < 32) s_qpk[buf * 32 + tid] = (nxt_pop << 16) | (unsigned)(qt * 32 + tid);
-        };
-        __syncthreads();                                       // the previous pass has finished reading both buffers
-        fetch(0); stage(0, 0);
+        __syncthreads();                                       // the previous pass has finished reading both buffers (and s_qpop is complete)
+#pragma unroll
+        for (int u = 0; u < MM_PF; ++u) ring[u] = fetch(u);    // tiles 0 .. MM_PF - 1 in flight
+        stage(0, 0, ring[0]);
+        ring[0] = fetch(MM_PF);
         __syncthreads();
-        for (int qt = 0; qt < ntq; ++qt) {
-            const int buf = qt & 1;
-            if (qt + 1 < ntq) fetch(qt + 1);                   // global loads of the next tile in flight during the MFMAs
-            if (tt < ntt) {
-                v16i_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int qt0 = 0; qt0 < ntq; qt0 += MM_PF) {
 #pragma unroll
-                for (int sK = 0; sK < 8; ++sK)
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(s_a[(buf * 8 + sK) * 64 + lane], bop[sK], acc, 0, 0, 0);
-                // C layout (dtype independent): column = lane & 31, row of register r = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+            for (int u = 0; u < MM_PF; ++u) {
+                const int qt = qt0 + u;
+                if (qt < ntq) {                                // workgroup-uniform
+                    const int buf = qt & 1;
+                    if (tt < ntt) {
+                        v16i_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned qpk = s_qpk[buf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
-                    best_key = min(best_key, (unsigned)__mul24(acc[r], -131072) + qpk);     // (|q| + 512 - 2 q.t) << 16 | queryIdx
+                        for (int sK = 0; sK < 8; ++sK)
+                            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(s_a[(buf * 8 + sK) * 64 + lane], bop[sK], acc, 0, 0, 0);
+                        // C layout (dtype independent): column = lane & 31, row of register r = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const unsigned qpk = s_qpk[buf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+                            best_key = min(best_key, (unsigned)__mul24(acc[r], -131072) + qpk);     // (|q| + 512 - 2 q.t) << 16 | queryIdx
+                        }
+                    }
+                    if (qt + 1 < ntq) {
+                        // tile qt + 1 sits in ring slot (u + 1) % MM_PF (tile 0 of this pass was staged in the prologue)
+                        stage(qt + 1, buf ^ 1, ring[(u + 1) % MM_PF]);
+                        ring[(u + 1) % MM_PF] = fetch(qt + 1 + MM_PF);
+                    }
+                    __syncthreads();
                 }
             }
-            if (qt + 1 < ntq) stage(qt + 1, buf ^ 1);
-            __syncthreads();
         }
         best_key = min(best_key, (unsigned)__shfl_xor((int)best_key, 32));
         if (valid_t && h == 0) {
