@@ -254,8 +254,12 @@ def run_workload(args, method, sub, data, rank, world, device, comm_kind):
     if world > 1:
         assert S == 1 and sub >= B, "multi-GPU runs use one handle and one launch group per rank"
         if comm_kind == "rccl":
-            comm = sharding.PoseComm(eng, rank, world, tag=f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{args.config}{int(args.stream)}")
-        else:
+            try:
+                comm = sharding.PoseComm(eng, rank, world, tag=f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{args.config}{int(args.stream)}")
+            except Exception as exc:       # librccl missing / bootstrap refused on this node: say so and still deliver the records
+                sys.stderr.write(f"[bench] rank {rank}: native RCCL pose gather unavailable ({exc}); using torch.distributed gloo for the 128-B records\n")
+                comm_kind = "gloo (RCCL gather unavailable)"
+        if comm is None:
             import torch.distributed as dist
             if not dist.is_initialized():
                 dist.init_process_group("gloo")
@@ -421,7 +425,7 @@ def run_workload(args, method, sub, data, rank, world, device, comm_kind):
                                     f"top-{args.max_matches}+5pt-RANSAC+recoverPose (BASELINE configs[2]" + ("" if B >= 4096 else f" shape, {B} of its 4096 pairs") + ")"),
                        "pairs_per_gpu": B, "distinct_pairs": data["distinct"], "global_pairs": world * B, "streams_per_gpu": S, "pairs_per_launch": Bl,
                        "sharding": f"pairs x{world}, " + ("rpe_gather_poses: ncclAllGather (RCCL) of 128-B pose records, no torch" if comm_kind == "rccl" or world == 1
-                                                         else "torch.distributed gloo all-gather of 128-B pose records (rehearsal)")},
+                                                         else f"torch.distributed all-gather of 128-B pose records: {comm_kind}")},
             "median_rotation_error_deg": float(np.median(errs)) if len(errs) else None,
             "median_translation_dir_error_deg": float(np.median(terrs)) if len(terrs) else None,
             "pairs_ok": int(ok.sum()),
