@@ -847,7 +847,7 @@ void rpe_launch_keypoints(rpe_handle *h, int n_img)
 
 // ------------------------------------------------- orientation + descriptor
 // Fused per-keypoint kernel (replaces the separate ICAngles, whole-pyramid GaussianBlur
-// and rBRIEF launches of the first version): one wave per keypoint, 4 keypoints per
+// and rBRIEF launches of the first version): one wave per keypoint, KP_PER_WG (= 1) keypoints per
 // workgroup.  The 45 x 48-byte raw patch around the keypoint is staged in LDS once and
 // feeds (1) the intensity-centroid moments over the radius-15 disc -> fastAtan2 angle,
 // (2) the horizontal pass of the fixed-point 7x7 Gaussian on the rows the descriptor can
