@@ -25,7 +25,11 @@
 #include <math.h>
 #include <string.h>
 #include <vector>
+#include <utility>
 
+// lanes of one wave exchanging data through LDS: the hardware runs a wave's LDS instructions in order, so all that is
+// needed is that the compiler keeps them in program order and does not move them across the point
+#define S_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define S_NOL 3
 #define S_NG 6
 #define S_ND 5
@@ -122,25 +126,56 @@ __global__ __launch_bounds__(256) void sift_blur_col_kernel(const float *__restr
     dst[(long long)blockIdx.z * dstride + (size_t)y * w + x] = acc;
 }
 
-// Fused separable Gaussian + DoG: one workgroup = 64x64 output pixels of one pyramid level.
-// The (64+2R)^2 source window (reflect-101 resolved at load time) is staged in LDS once, the row
-// pass runs on all 64+2R window rows into a second LDS plane, the column pass reads that plane and
-// writes G[i]; DoG[i-1] = G[i] - G[i-1] comes from the window centre, so the level is read once and
-// the two results are written once (the unfused version went through HBM between the passes and
-// read every level again for the DoG).  Each lane accumulates 8 neighbouring outputs from a
-// register window of 8+2R values; tap order and accumulation order are the oracle's
-// (acc = 0; acc += k[i]*v[i], i ascending), so the f32 results are bit-identical.
+// Fused separable Gaussian: one workgroup = 64 x TH output pixels of one pyramid level.
+// The (64+2R) x (TH+2R) source window (reflect-101 resolved at load time) is staged in LDS once, the
+// row pass runs on all TH+2R window rows into a second LDS plane, the column pass reads that plane
+// and writes G[i]: the level is read once and written once (the unfused version went through HBM
+// between the passes).  Each lane accumulates 8 outputs from a register window of 8+2R values; tap
+// order and accumulation order are the oracle's (acc = 0; acc += k[i]*v[i], i ascending), so the
+// f32 results are bit-identical.
+__device__ __forceinline__ void asm_pin(float __attribute__((ext_vector_type(2))) &p) { asm volatile("" : "+v"(p)); }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// P[m] = (lds[addr + 4*m*S], lds[addr + 4*(m+4)*S]) for every m of the sequence, S = 1 (ds_read2_b32) or 64 dwords
+// (ds_read2st64_b32); all reads are issued before the one wait.  Inline asm because the offsets must be chosen per
+// instruction; the compiler's own LDS wait counting does not see these, hence the explicit s_waitcnt and the pins.
+__device__ __forceinline__ unsigned lds_addr(const float *p)     // byte offset inside the workgroup's LDS allocation
+{
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
+}
+template <bool ST64, int M>
+__device__ __forceinline__ void lds_pair(f32x2 &p, unsigned addr)
+{
+    if (ST64) asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(p) : "v"(addr), "n"(M), "n"(M + 4) : "memory");
+    else      asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(p) : "v"(addr), "n"(M), "n"(M + 4) : "memory");
+}
+template <int... Ms>
+__device__ __forceinline__ void lds_pairs_sw(f32x2 *P, const unsigned *base4, std::integer_sequence<int, Ms...>)   // base by (m & 3)
+{
+    (lds_pair<true, Ms>(P[Ms], base4[Ms & 3]), ...);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    (asm_pin(P[Ms]), ...);
+}
+template <bool ST64, int... Ms>
+__device__ __forceinline__ void lds_pairs(f32x2 *P, unsigned addr, std::integer_sequence<int, Ms...>)
+{
+    (lds_pair<ST64, Ms>(P[Ms], addr), ...);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    (asm_pin(P[Ms]), ...);
+}
 template <int R, int TH>
 __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__restrict__ src, long long sstride, float *__restrict__ dst,
-                                                               long long dstride, float *__restrict__ dog, long long dogstride,
-                                                               int w, int h, int kid, int tcols, int ntiles)
+                                                               long long dstride, int w, int h, int kid, int tcols, int ntiles)
 {
     // TH = tile height: the LDS footprint (WINH x (SP + 64) floats) decides how many workgroups a CU holds; at R >= 8 a
     // 64-row tile leaves 2 per CU and the kernel waits on its own window loads, a 32-row tile fits 4 (and 6 at R = 5, 6,
     // where it measured 1.5 % faster than 64 rows despite the taller halo)
-    constexpr int WIN = 64 + 2 * R, WINH = TH + 2 * R, SP = WIN + 1, KS = 2 * R + 1;
-    __shared__ float s_src[WINH * SP];
+    constexpr int WIN = 64 + 2 * R, WINH = TH + 2 * R, KS = 2 * R + 1;
+    constexpr int HAL = (R + 3) & ~3, NCH = (64 + 2 * HAL) / 4;            // interior fast path: 16-B chunks from x0 - HAL on
+    // a window row = [WIN values][PADF spare]: the fast path stores whole chunks, and the HAL - R columns a chunk row has on
+    // either side of the window fall into the spare floats (of the row before / of the row itself); odd stride for the banks
+    constexpr int PADF = HAL - R, SP = (WIN + PADF) | 1;
+    __shared__ __attribute__((aligned(16))) float s_win[PADF + WINH * SP];
+    float *const s_src = s_win + PADF;
     __shared__ float s_tmp[WINH * 64];
     const int tid = threadIdx.x;
     // XCD-aware order: each XCD walks a contiguous raster run of tiles, so neighbouring windows (2R-wide shared halos)
@@ -149,35 +184,35 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
     if (ti >= ntiles) return;
     const int x0 = (ti % tcols) * 64, y0 = (ti / tcols) * TH;
     const float *s = src + (long long)blockIdx.y * sstride;
-    constexpr int HAL = (R + 3) & ~3, NCH = (64 + 2 * HAL) / 4;            // interior fast path: 16-B chunks from x0 - HAL on
     if (x0 >= HAL && x0 + 64 + HAL <= w && y0 >= R && y0 + TH + R <= h) {
         // Interior tile (91 % of the tiles of a 3840 x 2160 octave): no reflection anywhere, so the window is fetched as
-        // global_load_dwordx4 chunks (4-byte aligned is all the hardware asks of a multi-dword load) -- 6 loads and ~100
-        // vector instructions per lane instead of 22 dword loads with ~20 instructions of index / reflection arithmetic
-        // each (the load phase was 44 % of this issue-bound kernel's instructions).
-        constexpr int NLD4 = (WINH * NCH + 255) / 256;
+        // global_load_dwordx4 chunks (4-byte aligned is all the hardware asks of a multi-dword load).  A lane keeps its
+        // chunk column and walks down the rows (RPP rows per pass), so addresses and LDS offsets advance by wave-uniform
+        // constants: ~25 vector instructions per lane for the whole window (per-chunk index arithmetic and guarded
+        // element stores were ~100, a fifth of this issue-bound kernel).
+        constexpr int RPP = 256 / NCH, NQ = (WINH + RPP - 1) / RPP;
         typedef float f4_t __attribute__((ext_vector_type(4)));
-        f4_t stage[NLD4];
-        const float *org = s + (size_t)(y0 - R) * w + (x0 - HAL);
+        f4_t stage[NQ];
+        // lanes past the last chunk of a pass and rows past the window repeat the last valid chunk / row: same address,
+        // same data, so their loads and stores are harmless duplicates and nothing is predicated
+        const int t = min(tid, RPP * NCH - 1);
+        const int lr = t / NCH, c4 = t - lr * NCH;
+        const float *a = s + (size_t)(y0 - R + lr) * w + (x0 - HAL + 4 * c4);
+        float *d = s_src + lr * SP + 4 * c4 - PADF;
+        constexpr int LASTQ = NQ - 1, LAST_FULL = RPP * NQ <= WINH;
+        const int lrl = LAST_FULL ? lr : min(lr, WINH - 1 - RPP * LASTQ);   // row of the last pass, clamped into the window
 #pragma unroll
-        for (int q = 0; q < NLD4; ++q) {
-            const int i = min(tid + 256 * q, WINH * NCH - 1);
-            const int r = i / NCH, c4 = i - r * NCH;
-            const float *a = org + (size_t)r * w + 4 * c4;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stage[q]) : "v"(a) : "memory");      // kept in flight together
+        for (int q = 0; q < NQ; ++q) {
+            const float *aq = q < LASTQ ? a + (size_t)(RPP * q) * w : a + (size_t)(RPP * q + lrl - lr) * w;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stage[q]) : "v"(aq) : "memory");   // all in flight together
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int q = 0; q < NLD4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             asm volatile("" : "+v"(stage[q]));
-            const int i = tid + 256 * q;
-            const int r = i / NCH, c4 = i - r * NCH;
-            if (i < WINH * NCH) {
-                const int c = 4 * c4 - (HAL - R);                 // window column of the chunk's first element
-                float *d = s_src + r * SP + c;
+            float *dq = q < LASTQ ? d + RPP * q * SP : d + (RPP * q + lrl - lr) * SP;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (c + e >= 0 && c + e < WIN) d[e] = stage[q][e];
-            }
+            for (int e = 0; e < 4; ++e) dq[e] = stage[q][e];
         }
     } else if (w > R && h > R) {
         // window load, all requests in flight before the first LDS store: with one reflection being
@@ -213,51 +248,76 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
     __syncthreads();
     // Both passes: a lane produces 8 outputs as 4 packed pairs (j, j+4); the tap window is held as
     // pairs P[m] = (v[m], v[m+4]) so that every multiply and add is a v_pk_*_f32 (two IEEE f32
-    // operations per instruction, same rounding as the scalar ones: no contraction).
-    // row pass: item = (window row, group of 8 columns)
-    for (int it = tid; it < WINH * 8; it += 256) {
-        const int r = it >> 3, g = it & 7;
-        const float *row = s_src + r * SP + 8 * g;
+    // operations per instruction, same rounding as the scalar ones: no contraction).  The pairs come
+    // straight out of LDS: ds_read2_b32 / ds_read2st64_b32 take two independent offsets, so one
+    // instruction returns (v[m], v[m+4]) in an aligned register pair (left to the compiler the loads
+    // pair up as (v[m], v[m+1]) and 40 v_mov per item rebuild the operands: 16 % of the kernel).
+    // The first product starts the sum: taps and pixels are >= 0, so 0 + k*v == k*v bit for bit.
+    // row pass: item = (window row, group of 8 columns).  Lane -> item so that a 32-lane half holds 8 rows x 4 groups:
+    // its read addresses r * SP + 8 g + m (SP odd) then fall on 32 different banks (rows x 8 groups would alias g and
+    // g + 4).  The row-pass plane is stored with the column XORed by (row & 3): a plain [row][64] store would put all 32
+    // lanes of a half on 4 banks (8-way); swizzled it is 2-way, which a store does not feel.
+    for (int it = tid; it < (WINH + 7) / 8 * 64; it += 256) {
+        const int g = ((it >> 3) & 4) | (it & 3), r = (it >> 6) * 8 + ((it >> 2) & 7);
+        if (r >= WINH) continue;
         f32x2 P[4 + 2 * R];
-#pragma unroll
-        for (int m = 0; m < 4 + 2 * R; ++m) { P[m].x = row[m]; P[m].y = row[m + 4]; }
+        lds_pairs<false>(P, lds_addr(s_src + r * SP + 8 * g), std::make_integer_sequence<int, 4 + 2 * R>());
+        float *o = s_tmp + r * 64 + 8 * g;
+        float *const o0 = o + (0 ^ (r & 3)), *const o1 = o + (1 ^ (r & 3)), *const o2 = o + (2 ^ (r & 3)), *const o3 = o + (3 ^ (r & 3));
+        float *const oj[4] = {o0, o1, o2, o3};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            f32x2 acc = {0.f, 0.f};
+            f32x2 acc = f32x2{k[0], k[0]} * P[j];
 #pragma unroll
-            for (int i = 0; i < KS; ++i) { const f32x2 kk = {k[i], k[i]}; acc += kk * P[j + i]; }
-            s_tmp[r * 64 + 8 * g + j] = acc.x;
-            s_tmp[r * 64 + 8 * g + j + 4] = acc.y;
+            for (int i = 1; i < KS; ++i) { const f32x2 kk = {k[i], k[i]}; acc += kk * P[j + i]; }
+            oj[j][0] = acc.x;
+            oj[j][4] = acc.y;
         }
     }
     __syncthreads();
-    // column pass: item = (column, group of 8 rows)
-    const long long ob = (long long)blockIdx.y * dstride, db = (long long)blockIdx.y * dogstride;
-    for (int it = tid; it < 64 * (TH / 8); it += 256) {
-        const int c = it & 63, g = it >> 6;
-        const float *col = s_tmp + (8 * g) * 64 + c;
+    // column pass: a wave owns 8-row groups of the tile, a lane one column.  Stores are issue-bound per instruction
+    // (8 dword stores per lane cost a third of the kernel), so inside the image the wave turns its 8 x 64 results through
+    // LDS (the window plane is dead after the row pass; each wave uses its own 2 KB of it, no barrier) and writes them as
+    // two 16-byte stores per lane = four 256-byte rows per instruction.
+    const int lane = tid & 63;
+    const int x = x0 + lane;
+    const long long ob = (long long)blockIdx.y * dstride;
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    for (int g = __builtin_amdgcn_readfirstlane(tid >> 6); g < TH / 8; g += 4) {
         f32x2 P[4 + 2 * R];
-#pragma unroll
-        for (int m = 0; m < 4 + 2 * R; ++m) { P[m].x = col[m * 64]; P[m].y = col[(m + 4) * 64]; }
-        const int x = x0 + c;
-        // one 64-bit address per lane, rows by wave-uniform multiples of w (the per-output y * w + x in 64 bits was ~10
-        // instructions for each of the 16 stores)
-        const size_t o0 = (size_t)(y0 + 8 * g) * w + x;
-        float *pd = dst + ob + o0, *pg = dog ? dog + db + o0 : nullptr;
-        const int rows_left = x < w ? h - (y0 + 8 * g) : 0;
+        // rows 8 g + m and 8 g + m + 4 share (row & 3) = m & 3: one base address per residue undoes the swizzle
+        const unsigned cb = lds_addr(s_tmp + (8 * g) * 64);
+        const unsigned base4[4] = {cb + 4 * (lane ^ 0), cb + 4 * (lane ^ 1), cb + 4 * (lane ^ 2), cb + 4 * (lane ^ 3)};
+        lds_pairs_sw(P, base4, std::make_integer_sequence<int, 4 + 2 * R>());
+        const int yb = y0 + 8 * g;
+        float *pd = dst + ob + (size_t)yb * w + x0;
+        const int rows_left = h - yb;
+        const bool whole = rows_left >= 8 && x0 + 64 <= w;      // wave-uniform
+        float *so = s_win + (8 * g) * 64;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            f32x2 acc = {0.f, 0.f};
+            f32x2 acc = f32x2{k[0], k[0]} * P[j];
 #pragma unroll
-            for (int i = 0; i < KS; ++i) { const f32x2 kk = {k[i], k[i]}; acc += kk * P[j + i]; }
+            for (int i = 1; i < KS; ++i) { const f32x2 kk = {k[i], k[i]}; acc += kk * P[j + i]; }
+            if (whole) {
+                so[j * 64 + lane] = acc.x;
+                so[(j + 4) * 64 + lane] = acc.y;
+            } else {
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int yl = j + 4 * hh, yy = 8 * g + yl;
-                const float a = hh ? acc.y : acc.x;
-                if (yl < rows_left) {
-                    pd[(size_t)yl * w] = a;
-                    if (pg) pg[(size_t)yl * w] = a - s_src[(yy + R) * SP + c + R];
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int yl = j + 4 * hh;
+                    if (yl < rows_left && x < w) (pd + (size_t)yl * w)[lane] = hh ? acc.y : acc.x;
                 }
+            }
+        }
+        if (whole) {
+            const int rr = lane >> 4, c4 = (lane & 15) * 4;
+            const unsigned voff = (unsigned)(rr * w + c4) * 4u;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f4_t v = *(const f4_t *)(so + (4 * t + rr) * 64 + c4);
+                // scalar row base + 32-bit lane offset
+                asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(voff), "v"(v), "s"(pd + (size_t)(4 * t) * w) : "memory");
             }
         }
     }
@@ -586,8 +646,12 @@ __global__ __launch_bounds__(256) void sift_orient_kernel(const float *__restric
     const float sigma = 1.5f * scl_octv;
     const float expf_scale = -1.f / (2.f * sigma * sigma);
     const float *img_l = gauss + (long long)img * dv.gstride + dv.goff[o] + (long long)l * n;
-    volatile float (*part)[8] = s_part[wv];
-    for (int i = lane; i < S_BINS * 8; i += 64) ((volatile float *)part)[i] = 0.f;
+    // LDS accessed as LDS (ds_* instructions, in order within the wave); S_WAVE_SYNC orders the lanes' accesses for the
+    // compiler.  (Through a volatile generic pointer every access became a flat_* instruction with system-scope cache
+    // bits and a full wait: 16 serialized round trips per 64 samples.)
+    float (*part)[8] = s_part[wv];
+    for (int i = lane; i < S_BINS * 8; i += 64) (&part[0][0])[i] = 0.f;
+    S_WAVE_SYNC();
     const int side = 2 * radius + 1, nsamp = side * side;
     const float inv_side = 1.f / (float)side;
     constexpr int DU = 4;                                   // batches whose gradient loads fly together
@@ -631,11 +695,11 @@ __global__ __launch_bounds__(256) void sift_orient_kernel(const float *__restric
 #pragma unroll
             for (int rd = 0; rd < 8; ++rd) {
                 if ((lane >> 3) == rd && valid) part[bin][lane & 7] = part[bin][lane & 7] + contrib;
-                __builtin_amdgcn_wave_barrier();
+                S_WAVE_SYNC();
             }
         }
     }
-    volatile float *th = s_hist[wv] + 2;
+    float *th = s_hist[wv] + 2;
     if (lane < S_BINS) {
         float p0 = part[lane][0], p1 = part[lane][1], p2 = part[lane][2], p3 = part[lane][3];
         float p4 = part[lane][4], p5 = part[lane][5], p6 = part[lane][6], p7 = part[lane][7];
@@ -643,9 +707,9 @@ __global__ __launch_bounds__(256) void sift_orient_kernel(const float *__restric
         p0 = p0 + p2; p1 = p1 + p3;
         th[lane] = p0 + p1;
     }
-    __builtin_amdgcn_wave_barrier();
+    S_WAVE_SYNC();
     if (lane == 0) { th[-1] = th[S_BINS - 1]; th[-2] = th[S_BINS - 2]; th[S_BINS] = th[0]; th[S_BINS + 1] = th[1]; }
-    __builtin_amdgcn_wave_barrier();
+    S_WAVE_SYNC();
     float hv = -1.f;
     if (lane < S_BINS)
         hv = (th[lane - 2] + th[lane + 2]) * (1.f / 16.f) + (th[lane - 1] + th[lane + 1]) * (4.f / 16.f) + th[lane] * (6.f / 16.f);
@@ -665,7 +729,7 @@ __global__ __launch_bounds__(256) void sift_orient_kernel(const float *__restric
             q[0] = kx; q[1] = ky; q[2] = ksize; q[3] = angle; q[4] = kresp; q[5] = __int_as_float(koct);
         } else atomicOr(&overflow[img], (unsigned)RPE_OVF_SIFT_RAW);
     }
-    __builtin_amdgcn_wave_barrier();
+    S_WAVE_SYNC();
     }
 }
 
@@ -874,9 +938,10 @@ __global__ __launch_bounds__(64 * SIFT_DESC_KPW) void sift_describe_kernel(const
     const int rmax = (int)sqrt(((double)w) * w + ((double)h) * h);
     if (radius > rmax) radius = rmax;
     cos_t /= hist_width; sin_t /= hist_width;
-    volatile float (*part)[8] = s_part[wv];
-    volatile float *stg = s_stage[wv];
-    for (int i = lane; i < 360 * 8; i += 64) ((volatile float *)part)[i] = 0.f;
+    float (*part)[8] = s_part[wv];
+    float *stg = s_stage[wv];
+    for (int i = lane; i < 360 * 8; i += 64) (&part[0][0])[i] = 0.f;
+    S_WAVE_SYNC();
     const int side = 2 * radius + 1, nsamp = side * side;
     const float inv_side = 1.f / (float)side;
     // DU batches of 64 samples per trip: the 4*DU gradient loads of a lane are issued before anything
@@ -938,7 +1003,7 @@ __global__ __launch_bounds__(64 * SIFT_DESC_KPW) void sift_describe_kernel(const
         stg[lane * 9] = valid ? __int_as_float(idx) : __int_as_float(-1);
         stg[lane * 9 + 1] = v000; stg[lane * 9 + 2] = v001; stg[lane * 9 + 3] = v010; stg[lane * 9 + 4] = v011;
         stg[lane * 9 + 5] = v100; stg[lane * 9 + 6] = v101; stg[lane * 9 + 7] = v110; stg[lane * 9 + 8] = v111;
-        __builtin_amdgcn_wave_barrier();
+        S_WAVE_SYNC();
         {
             const int sl = lane & 7, q = lane >> 3;
             const int qoff = (q & 1) + ((q >> 1) & 1) * (n + 2) + (q >> 2) * (d + 2) * (n + 2);
@@ -948,19 +1013,20 @@ __global__ __launch_bounds__(64 * SIFT_DESC_KPW) void sift_describe_kernel(const
                 const int id = __float_as_int(stg[kl * 9]);
                 const float v = stg[kl * 9 + 1 + q];
                 if (id >= 0) part[id + qoff][sl] = part[id + qoff][sl] + v;
-                __builtin_amdgcn_wave_barrier();
+                S_WAVE_SYNC();
             }
         }
         }
     }
-    volatile float *hist = s_hist[wv];
+    S_WAVE_SYNC();
+    float *hist = s_hist[wv];
     for (int b = lane; b < 360; b += 64) {
         float p0 = part[b][0], p1 = part[b][1], p2 = part[b][2], p3 = part[b][3], p4 = part[b][4], p5 = part[b][5], p6 = part[b][6], p7 = part[b][7];
         p0 = p0 + p4; p1 = p1 + p5; p2 = p2 + p6; p3 = p3 + p7;
         p0 = p0 + p2; p1 = p1 + p3;
         hist[b] = p0 + p1;
     }
-    __builtin_amdgcn_wave_barrier();
+    S_WAVE_SYNC();
     // circular orientation bins, then element e = (i*d + j)*n + k ; lane holds e = lane and lane + 64
     float dv0, dv1;
     {
@@ -1095,8 +1161,11 @@ static void sift_blur_launch(rpe_handle *h, const float *src, long long sstride,
 {
     constexpr int TH = 32;
     const int tcols = (w + 63) / 64, ntiles = tcols * ((hh + TH - 1) / TH);
-    hipLaunchKernelGGL((sift_blur_fused_kernel<R, TH>), dim3((ntiles + 7) / 8 * 8, n_img), dim3(256), 0, h->stream, src, sstride, dst, dstride, dog, dogstride,
+    hipLaunchKernelGGL((sift_blur_fused_kernel<R, TH>), dim3((ntiles + 7) / 8 * 8, n_img), dim3(256), 0, h->stream, src, sstride, dst, dstride,
                        w, hh, kid, tcols, ntiles);
+    if (dog)      // DoG planes are not stored by the product path (layers are formed where they are consumed); kept for callers that ask
+        hipLaunchKernelGGL(sift_sub_kernel, dim3((unsigned)(((long long)w * hh + 255) / 256), 1, n_img), dim3(256), 0, h->stream,
+                           (const float *)dst, dstride, src, sstride, dog, dogstride, (long long)w * hh);
 }
 
 // G[dst] = gauss(kid) * G[src]; dog (optional) = G[dst] - G[src]
