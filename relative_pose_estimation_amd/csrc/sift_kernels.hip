@@ -604,7 +604,8 @@ __global__ __launch_bounds__(256) void sift_adjust_kernel(const float *__restric
                                                            const unsigned *__restrict__ seeds, const int *__restrict__ nseeds,
                                                            float *__restrict__ surv, int *__restrict__ nsurv)
 {
-    const int sidx = blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
+    // image = fastest grid dimension (see sift_orient_kernel: the survivors' atomicAdd(&nsurv[img]) spread over the images)
+    const int sidx = blockIdx.y * 256 + threadIdx.x, img = blockIdx.x;
     if (sidx >= nseeds[img]) return;
     const unsigned sd = seeds[(long long)img * dv.seed_cap + sidx];
     const int o = sd >> 28;
@@ -619,17 +620,24 @@ __global__ __launch_bounds__(256) void sift_adjust_kernel(const float *__restric
     q[1] = xi; q[2] = xr; q[3] = xc; q[4] = contr;
 }
 
-// (112 VGPRs = 4 waves per SIMD; forcing 5, 6 or 8 through __launch_bounds__ changed nothing: 22.2 -> 21.5 / 22.2 / 23.0 ms)
-__global__ __launch_bounds__(256) void sift_orient_kernel(const float *__restrict__ gauss, SiftDev dv,
+// One wave per workgroup: survivors differ in window size (6 to 14+ batches of 64 samples), and a 4-wave workgroup
+// holds its wave slots and LDS until its slowest wave is done.
+#define SIFT_ORI_WPW 1
+#define S_ORI_RMAX1 20      // radius + 1 <= 18: radius = round(4.5 * 1.6 * 2^((l + xi) / 3)), l <= 3, |xi| < 0.5 -> <= 17
+__global__ __launch_bounds__(64 * SIFT_ORI_WPW) void sift_orient_kernel(const float *__restrict__ gauss, SiftDev dv,
                                                            const float *__restrict__ surv, const int *__restrict__ nsurv,
                                                            float *__restrict__ raw, int *__restrict__ nraw, unsigned *__restrict__ overflow)
 {
-    __shared__ float s_part[4][S_BINS][8];
-    __shared__ float s_hist[4][S_BINS + 4];
+    __shared__ float s_part[SIFT_ORI_WPW][S_BINS][8];
+    __shared__ float s_hist[SIFT_ORI_WPW][S_BINS + 4];
+    __shared__ float s_wtab[SIFT_ORI_WPW][S_ORI_RMAX1 * S_ORI_RMAX1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int img = blockIdx.y, ns = nsurv[img];
+    // image = fastest grid dimension: workgroups in flight together then belong to different images and their
+    // atomicAdd(&nraw[img]) go to different addresses (with one image at a time 14 k returning atomics per image queued
+    // on a single L2 line: 12 of this kernel's 20 ms)
+    const int img = blockIdx.x, ns = nsurv[img];
     // waves stride over the survivor list (a grid sized for seed_cap would be millions of empty workgroups)
-    for (int sidx = blockIdx.x * 4 + wv; sidx < ns; sidx += gridDim.x * 4) {
+    for (int sidx = blockIdx.y * SIFT_ORI_WPW + wv; sidx < ns; sidx += gridDim.y * SIFT_ORI_WPW) {
     const float *sq = surv + ((long long)img * dv.seed_cap + sidx) * SURV_W;
     const unsigned sd = (unsigned)__float_as_int(sq[0]);
     const int o = sd >> 28, l = (sd >> 26) & 3, r = (sd >> 13) & 0x1FFF, c = sd & 0x1FFF;
@@ -652,22 +660,40 @@ __global__ __launch_bounds__(256) void sift_orient_kernel(const float *__restric
     float (*part)[8] = s_part[wv];
     for (int i = lane; i < S_BINS * 8; i += 64) (&part[0][0])[i] = 0.f;
     S_WAVE_SYNC();
+    // Gaussian weights: exp((i*i + j*j) * expf_scale) is the same number for the up to 8 samples (+-i, +-j), (+-j, +-i),
+    // and det_expf (22 dependent f64 operations) was 60 % of this kernel: evaluate it once per pair a <= b into an LDS
+    // table.  Rows a and radius - a of the triangle together have radius + 2 entries, so the triangle is walked as a
+    // ceil((radius+1)/2) x (radius+2) rectangle: 2 rounds of 64 lanes at radius 14 instead of 14 batches of samples.
+    float *wtab = s_wtab[wv];
+    const int r1 = radius + 1;
+    if (r1 <= S_ORI_RMAX1) {
+        const int wdt = radius + 2, nent = ((r1 + 1) >> 1) * wdt;
+        for (int t = lane; t < nent; t += 64) {
+            const int q = t / wdt, e = t - q * wdt;
+            const bool first = e < r1 - q;
+            const int a = first ? q : radius - q, b = first ? q + e : radius - q + (e - (r1 - q));
+            if (first || q < radius - q) wtab[a * r1 + b] = det_expf((float)(a * a + b * b) * expf_scale);
+        }
+    }
+    S_WAVE_SYNC();
     const int side = 2 * radius + 1, nsamp = side * side;
     const float inv_side = 1.f / (float)side;
     constexpr int DU = 4;                                   // batches whose gradient loads fly together
+    const int kl = ((lane & 7) << 3) | (lane >> 3);         // sample of a 64-batch held by this lane: slot k & 7 = lane >> 3
     for (int k0 = 0; k0 < nsamp; k0 += 64 * DU) {
         bool vld[DU];
-        int di2[DU];
+        int di2[DU], wix[DU];
         float g0[DU], g1[DU], g2[DU], g3[DU];
 #pragma unroll
         for (int u = 0; u < DU; ++u) {
-            const int k = k0 + 64 * u + lane;
+            const int k = k0 + 64 * u + kl;
             int qi = (int)((float)k * inv_side);
             int rem = k - qi * side;
             if (rem < 0) { --qi; rem += side; } else if (rem >= side) { ++qi; rem -= side; }
             const int i = qi - radius, j = rem - radius;
             const int y = r + i, x = c + j;
             di2[u] = i * i + j * j;
+            { const int ai = i < 0 ? -i : i, aj = j < 0 ? -j : j; wix[u] = min(ai, aj) * r1 + max(ai, aj); }
             vld[u] = k < nsamp && !(y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1);
             g0[u] = g1[u] = g2[u] = g3[u] = 0.f;
             if (vld[u]) {
@@ -683,7 +709,7 @@ __global__ __launch_bounds__(256) void sift_orient_kernel(const float *__restric
             if (valid) {
                 const float dx = g0[u] - g1[u];
                 const float dy = g2[u] - g3[u];
-                const float wgt = det_expf((float)di2[u] * expf_scale);
+                const float wgt = r1 <= S_ORI_RMAX1 ? wtab[wix[u]] : det_expf((float)di2[u] * expf_scale);
                 const float ori = fast_atan2_deg(dy, dx);
                 const float mag = sqrtf(dx * dx + dy * dy);
                 bin = __float2int_rn((S_BINS / 360.f) * ori);
@@ -691,11 +717,26 @@ __global__ __launch_bounds__(256) void sift_orient_kernel(const float *__restric
                 if (bin < 0) bin += S_BINS;
                 contrib = wgt * mag;
             }
-            // 8 rounds of 8 lanes: slot (lane & 7) receives its samples in ascending k
+            // Slot p = lane >> 3 receives its 8 samples of the batch in ascending k = ascending lane.  Each lane builds the
+            // value its accumulator has after its own sample: the accumulator as the previous batch left it, plus the
+            // contributions of the lanes before it in its group of 8 that hit the same bin (taken in lane order from
+            // the neighbours by DPP row shifts), plus its own.  The 8 masked stores then go out in lane order, so the
+            // last sample of a bin leaves the final value.  One LDS round trip per batch instead of 8 dependent ones;
+            // the additions and their order are those of the sequential loop.
+            {
+                const int binv = valid ? bin : -1;
+                float acc = valid ? part[bin][lane >> 3] : 0.f;
+#define S_ORI_STEP(s) { const int bs = __builtin_amdgcn_update_dpp(-2, binv, 0x110 + (s), 0xF, 0xF, false); \
+                        const float cs = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(contrib), 0x110 + (s), 0xF, 0xF, false)); \
+                        if (bs == binv && (lane & 7) >= (s)) acc = acc + cs; }
+                S_ORI_STEP(7) S_ORI_STEP(6) S_ORI_STEP(5) S_ORI_STEP(4) S_ORI_STEP(3) S_ORI_STEP(2) S_ORI_STEP(1)
+#undef S_ORI_STEP
+                acc = acc + contrib;
 #pragma unroll
-            for (int rd = 0; rd < 8; ++rd) {
-                if ((lane >> 3) == rd && valid) part[bin][lane & 7] = part[bin][lane & 7] + contrib;
-                S_WAVE_SYNC();
+                for (int rd = 0; rd < 8; ++rd) {
+                    if ((lane & 7) == rd && valid) part[bin][lane >> 3] = acc;
+                    S_WAVE_SYNC();
+                }
             }
         }
     }
@@ -1233,10 +1274,10 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
     hipMemsetAsync(S->d_nraw, 0, sizeof(int) * n, h->stream);
     MARK(h, RPE_STAGE_NMS); MARK(h, RPE_STAGE_SELECT);
     hipMemsetAsync(S->d_nsurv, 0, sizeof(int) * n, h->stream);
-    hipLaunchKernelGGL(sift_adjust_kernel, dim3((dv.seed_cap + 255) / 256, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
+    hipLaunchKernelGGL(sift_adjust_kernel, dim3(n, (dv.seed_cap + 255) / 256), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
                        (const unsigned *)S->d_seeds, (const int *)S->d_nseeds, S->d_surv, S->d_nsurv);
     MARK(h, RPE_STAGE_HARRIS);
-    hipLaunchKernelGGL(sift_orient_kernel, dim3(2048, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
+    hipLaunchKernelGGL(sift_orient_kernel, dim3(n, 8192 / SIFT_ORI_WPW), dim3(64 * SIFT_ORI_WPW), 0, h->stream, (const float *)S->d_gauss, dv,
                        (const float *)S->d_surv, (const int *)S->d_nsurv, S->d_raw, S->d_nraw, h->d_ovf);
     // 5. sort, dedup, retainBest, compaction
     MARK(h, RPE_STAGE_KEYPOINTS);
