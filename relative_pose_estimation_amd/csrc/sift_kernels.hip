@@ -70,24 +70,44 @@ struct RpeSiftState {
 };
 
 // ------------------------------------------------------------------ image ops
+// 2x INTER_LINEAR of the u8 image into f32 (oracle: sift_oracle.c upsample; cv2.resize semantics: source position
+// (x + 0.5) / 2 - 0.5, clamped at the borders).  The interpolation weights are 0.25 / 0.75 and the pixels are integers
+// below 256, so every product and sum of a*(1-f) + b*f is exact in f32 and any evaluation order gives the oracle's bits:
+// the kernel works in integers, out = (wy0 (wx0 s00 + wx1 s01) + wy1 (wx0 s10 + wx1 s11)) / 16 with weights 1 and 3.
+// A lane produces the 4 x 2 outputs x = 4t .. 4t+3, y = 2r+1, 2r+2 from source rows r, r+1 and columns 2t-1 .. 2t+2
+// (clamping the indices reproduces the border rule: a clamped pair has two equal values, and (1 v + 3 v) / 4 = v).
 __global__ __launch_bounds__(256) void sift_upsample_kernel(const uint8_t *__restrict__ img, int W, int H, size_t img_stride,
                                                              float *__restrict__ dst, long long dstride)
 {
-    const int bw = 2 * W;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= bw) return;
+    const int bw = 2 * W, bh = 2 * H;
+    const int t = blockIdx.x * 256 + threadIdx.x, r = (int)blockIdx.y - 1;       // r = -1 .. H-1
+    if (4 * t >= bw) return;
     const uint8_t *s = img + (size_t)blockIdx.z * img_stride;
-    float fy = (y + 0.5f) * 0.5f - 0.5f; int sy = (int)floorf(fy); fy -= sy;
-    if (sy < 0) { sy = 0; fy = 0.f; }
-    int sy1 = sy + 1 < H ? sy + 1 : H - 1;
-    if (sy >= H - 1) { sy = H - 1; sy1 = H - 1; fy = 0.f; }
-    float fx = (x + 0.5f) * 0.5f - 0.5f; int sx = (int)floorf(fx); fx -= sx;
-    if (sx < 0) { sx = 0; fx = 0.f; }
-    int sx1 = sx + 1 < W ? sx + 1 : W - 1;
-    if (sx >= W - 1) { sx = W - 1; sx1 = W - 1; fx = 0.f; }
-    float h0 = (float)s[(size_t)sy * W + sx] * (1.f - fx) + (float)s[(size_t)sy * W + sx1] * fx;
-    float h1 = (float)s[(size_t)sy1 * W + sx] * (1.f - fx) + (float)s[(size_t)sy1 * W + sx1] * fx;
-    dst[(long long)blockIdx.z * dstride + (size_t)y * bw + x] = h0 * (1.f - fy) + h1 * fy;
+    const uint8_t *ra = s + (size_t)max(r, 0) * W, *rb = s + (size_t)min(r + 1, H - 1) * W;
+    const int c0 = max(2 * t - 1, 0), c1 = min(2 * t, W - 1), c2 = min(2 * t + 1, W - 1), c3 = min(2 * t + 2, W - 1);
+    const unsigned a0 = ra[c0], a1 = ra[c1], a2 = ra[c2], a3 = ra[c3];
+    const unsigned b0 = rb[c0], b1 = rb[c1], b2 = rb[c2], b3 = rb[c3];
+    // horizontal: x = 4t: (c0, c1) weights (1, 3); 4t+1: (c1, c2) (3, 1); 4t+2: (c1, c2) (1, 3); 4t+3: (c2, c3) (3, 1)
+    const unsigned ha[4] = {a0 + 3 * a1, 3 * a1 + a2, a1 + 3 * a2, 3 * a2 + a3};
+    const unsigned hb[4] = {b0 + 3 * b1, 3 * b1 + b2, b1 + 3 * b2, 3 * b2 + b3};
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    f4_t o1, o2;                                                                   // rows 2r+1 (weights 3, 1) and 2r+2 (1, 3)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o1[j] = (float)(3 * ha[j] + hb[j]) * 0.0625f;
+        o2[j] = (float)(ha[j] + 3 * hb[j]) * 0.0625f;
+    }
+    float *d = dst + (long long)blockIdx.z * dstride + 4 * t;
+    const int y1 = 2 * r + 1, y2 = 2 * r + 2;
+    if (4 * t + 3 < bw) {
+        if (y1 >= 0) *(f4_t *)(d + (size_t)y1 * bw) = o1;
+        if (y2 < bh) *(f4_t *)(d + (size_t)y2 * bw) = o2;
+    } else {
+        for (int j = 0; j < 4 && 4 * t + j < bw; ++j) {
+            if (y1 >= 0) d[(size_t)y1 * bw + j] = o1[j];
+            if (y2 < bh) d[(size_t)y2 * bw + j] = o2[j];
+        }
+    }
 }
 
 __device__ __forceinline__ int s_refl(int p, int n)
@@ -1243,7 +1263,7 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
     for (int part = 0; part < 2; ++part) {
         const uint8_t *src = part ? d_b : d_a; const int cnt = part ? nb : na, first = part ? na : 0;
         if (!cnt) continue;
-        hipLaunchKernelGGL(sift_upsample_kernel, dim3((bw + 255) / 256, bh, cnt), dim3(256), 0, h->stream, src, W, H, img,
+        hipLaunchKernelGGL(sift_upsample_kernel, dim3((bw / 4 + 256) / 256, H + 1, cnt), dim3(256), 0, h->stream, src, W, H, img,
                            S->d_tmp + (long long)first * dv.tstride, dv.tstride);
     }
     const int n = na + nb;
