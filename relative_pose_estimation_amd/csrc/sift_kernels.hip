@@ -1068,12 +1068,14 @@ __global__ __launch_bounds__(64 * SIFT_DESC_KPW) void sift_describe_kernel(const
         {
             const int sl = lane & 7, q = lane >> 3;
             const int qoff = (q & 1) + ((q >> 1) & 1) * (n + 2) + (q >> 2) * (d + 2) * (n + 2);
+            // the 16 staged values of this lane's 8 steps are read in one go (they do not depend on the accumulators);
+            // the steps themselves stay sequential: corners of different samples share bins
+            int ids[8]; float vs[8];
+#pragma unroll
+            for (int st = 0; st < 8; ++st) { ids[st] = __float_as_int(stg[(sl + 8 * st) * 9]); vs[st] = stg[(sl + 8 * st) * 9 + 1 + q]; }
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
-                const int kl = sl + 8 * st;
-                const int id = __float_as_int(stg[kl * 9]);
-                const float v = stg[kl * 9 + 1 + q];
-                if (id >= 0) part[id + qoff][sl] = part[id + qoff][sl] + v;
+                if (ids[st] >= 0) part[ids[st] + qoff][sl] = part[ids[st] + qoff][sl] + vs[st];
                 S_WAVE_SYNC();
             }
         }
