@@ -411,15 +411,21 @@ __global__ __launch_bounds__(256) void sift_extrema_mask_kernel(const float *__r
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int NEL = (SX_TH + 2) * (SX_TW + 2), NLD = (NEL + 255) / 256;
     float stage[NLD], prevg[NLD];
+    // element q of this lane: clamped source offset inside a level (32-bit, the level base stays scalar) and LDS offset;
+    // both are the same for all six levels
+    unsigned goffs[NLD]; int loffs[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int i = min(tid + 256 * q, NEL - 1);
+        const int r = i / (SX_TW + 2), c = i - r * (SX_TW + 2);
+        const int y = min(max(y0 - 1 + r, 0), h - 1), x = min(max(x0 - 1 + c, 0), w - 1);
+        goffs[q] = (unsigned)(y * w + x);
+        loffs[q] = tid + 256 * q < NEL ? r * SX_P + c : -1;
+    }
     auto fetch = [&](int layer) {               // all loads of a Gaussian level in flight
         const float *src = d + layer * n;
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) {
-            const int i = min(tid + 256 * q, NEL - 1);
-            const int r = i / (SX_TW + 2), c = i - r * (SX_TW + 2);
-            const int y = min(max(y0 - 1 + r, 0), h - 1), x = min(max(x0 - 1 + c, 0), w - 1);
-            stage[q] = src[(size_t)y * w + x];
-        }
+        for (int q = 0; q < NLD; ++q) stage[q] = src[goffs[q]];
     };
     auto keep = [&]() {
 #pragma unroll
@@ -428,9 +434,7 @@ __global__ __launch_bounds__(256) void sift_extrema_mask_kernel(const float *__r
     auto commit = [&](int slot) {               // DoG = this level - the level below, into an LDS plane
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
-            const int i = tid + 256 * q;
-            const int r = i / (SX_TW + 2), c = i - r * (SX_TW + 2);
-            if (i < NEL) s_d[slot][r * SX_P + c] = stage[q] - prevg[q];
+            if (q < NLD - 1 || loffs[q] >= 0) s_d[slot][loffs[q]] = stage[q] - prevg[q];
             prevg[q] = stage[q];
         }
     };
@@ -440,44 +444,43 @@ __global__ __launch_bounds__(256) void sift_extrema_mask_kernel(const float *__r
     fetch(3);
     unsigned long long *mk = mask + (long long)img * dv.bmstride + dv.bmoff[o];
     int *bc = band_cnt + (long long)img * dv.nbands + dv.band0[o];
-    const int hcol = lane < 32 ? 0 : SX_TW + 1;            // halo column this lane can stand in for
     for (int l = 1; l <= S_NOL; ++l) {
         commit((l + 1) % 3);
         __syncthreads();
         if (l < S_NOL) fetch(l + 3);                        // next level's loads fly during the tests
         const float *lo = s_d[(l - 1) % 3], *mid = s_d[l % 3], *hi = s_d[(l + 1) % 3];
-        // rolling per-row layer max/min: own column and halo column
-        float pmx[3], pmn[3], hmx[3], hmn[3];
-        auto rowmm = [&](int lr, float &mx, float &mn, float &hx, float &hn) {       // lr = LDS row
-            const int q = lr * SX_P + lane + 1, qh = lr * SX_P + hcol;
-            const float a = lo[q], b = mid[q], c = hi[q];
-            mx = fmaxf(fmaxf(a, b), c); mn = fminf(fminf(a, b), c);
-            const float ah = lo[qh], bh = mid[qh], ch = hi[qh];
-            hx = fmaxf(fmaxf(ah, bh), ch); hn = fminf(fminf(ah, bh), ch);
+        // per LDS row: max / min over the 3 layers x 3 columns around this lane's pixel (the plane carries the halo
+        // columns, so the left / right neighbours are plain LDS reads: no cross-lane traffic, no halo special case);
+        // rolled over 3 rows it is the 27-value max / min.  ctr = the centre value of the row.
+        float pmx[3], pmn[3], ctr[3];
+        auto rowmm = [&](int lr, float &mx, float &mn, float &cv) {       // lr = LDS row
+            const int q = lr * SX_P + lane;
+            const float a0 = lo[q], a1 = lo[q + 1], a2 = lo[q + 2];
+            const float b0 = mid[q], b1 = mid[q + 1], b2 = mid[q + 2];
+            const float c0 = hi[q], c1 = hi[q + 1], c2 = hi[q + 2];
+            mx = fmaxf(fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(b0, b1), b2)), fmaxf(fmaxf(c0, c1), c2));
+            mn = fminf(fminf(fminf(fminf(a0, a1), a2), fminf(fminf(b0, b1), b2)), fminf(fminf(c0, c1), c2));
+            cv = b1;
         };
         const int rb = 8 * wv;                              // first output row of this wave (tile-relative)
-        rowmm(rb, pmx[0], pmn[0], hmx[0], hmn[0]);
-        rowmm(rb + 1, pmx[1], pmn[1], hmx[1], hmn[1]);
+        rowmm(rb, pmx[0], pmn[0], ctr[0]);
+        rowmm(rb + 1, pmx[1], pmn[1], ctr[1]);
+        const int x = x0 + lane;
+        const bool xin = x >= S_BORDER && x < w - S_BORDER;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int rr = rb + k, y = y0 + rr, x = x0 + lane;
-            rowmm(rr + 2, pmx[2], pmn[2], hmx[2], hmn[2]);
-            const float cmx = fmaxf(fmaxf(pmx[0], pmx[1]), pmx[2]), cmn = fminf(fminf(pmn[0], pmn[1]), pmn[2]);
-            const float hx = fmaxf(fmaxf(hmx[0], hmx[1]), hmx[2]), hn = fminf(fminf(hmn[0], hmn[1]), hmn[2]);
-            float lmx = dpp_wave_shr1(cmx), lmn = dpp_wave_shr1(cmn), rmx = dpp_wave_shl1(cmx), rmn = dpp_wave_shl1(cmn);
-            if (lane == 0) { lmx = hx; lmn = hn; }
-            if (lane == 63) { rmx = hx; rmn = hn; }
-            const float M = fmaxf(fmaxf(lmx, cmx), rmx), m = fminf(fminf(lmn, cmn), rmn);
-            const float val = mid[(rr + 1) * SX_P + lane + 1];
-            const bool hit = y >= S_BORDER && y < h - S_BORDER && x >= S_BORDER && x < w - S_BORDER && fabsf(val) > 1.f &&
-                             ((val > 0.f && val >= M) || (val < 0.f && val <= m));
+            const int rr = rb + k, y = y0 + rr;
+            rowmm(rr + 2, pmx[2], pmn[2], ctr[2]);
+            const float M = fmaxf(fmaxf(pmx[0], pmx[1]), pmx[2]), m = fminf(fminf(pmn[0], pmn[1]), pmn[2]);
+            const float val = ctr[1];
+            const bool yin = y >= S_BORDER && y < h - S_BORDER;       // wave-uniform
+            const bool hit = yin && xin && fabsf(val) > 1.f && ((val > 0.f && val >= M) || (val < 0.f && val <= m));
             const unsigned long long bal = __ballot(hit);
-            if (lane == 0 && y >= S_BORDER && y < h - S_BORDER) {
+            if (lane == 0 && yin) {
                 mk[((long long)(l - 1) * h + y) * dv.wpr[o] + (x0 >> 6)] = bal;
                 if (bal) atomicAdd(&bc[(l - 1) * (h - 2 * S_BORDER) + (y - S_BORDER)], __popcll(bal));
             }
-            pmx[0] = pmx[1]; pmx[1] = pmx[2]; pmn[0] = pmn[1]; pmn[1] = pmn[2];
-            hmx[0] = hmx[1]; hmx[1] = hmx[2]; hmn[0] = hmn[1]; hmn[1] = hmn[2];
+            pmx[0] = pmx[1]; pmx[1] = pmx[2]; pmn[0] = pmn[1]; pmn[1] = pmn[2]; ctr[0] = ctr[1]; ctr[1] = ctr[2];
         }
         __syncthreads();
     }
