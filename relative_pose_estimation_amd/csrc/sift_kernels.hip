@@ -1036,6 +1036,7 @@ __global__ __launch_bounds__(64 * SIFT_DESC_KPW) void sift_describe_kernel(const
         for (int u = 0; u < DU; ++u) {
         if (k0 + 64 * u >= nsamp) break;                                  // wave-uniform
         const bool valid = vld[u];
+        if (__ballot(valid) == 0) continue;        // 64 samples outside the rotated 4x4 grid (rows near the corners of its bounding square)
         int idx = 0;
         float v000 = 0, v001 = 0, v010 = 0, v011 = 0, v100 = 0, v101 = 0, v110 = 0, v111 = 0;
         if (valid) {
