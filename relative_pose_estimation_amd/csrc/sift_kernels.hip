@@ -343,13 +343,24 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
     }
 }
 
+// INTER_NEAREST octave decimation: dst(x, y) = src(2x, 2y).  A lane writes 4 neighbouring outputs with one 16-byte store
+// from two 16-byte loads (one dword per lane each way left this copy issue-bound in its many small launches).
 __global__ __launch_bounds__(256) void sift_halve_kernel(const float *__restrict__ src, float *__restrict__ dst, long long stride,
                                                           int sw, int w, int h)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int x = 4 * (blockIdx.x * 256 + threadIdx.x), y = blockIdx.y;
     if (x >= w) return;
     const long long b = (long long)blockIdx.z * stride;
-    dst[b + (size_t)y * w + x] = src[b + (size_t)(2 * y) * sw + 2 * x];
+    const float *sp = src + b + (size_t)(2 * y) * sw + 2 * x;
+    float *dp = dst + b + (size_t)y * w + x;
+    typedef float f4_t __attribute__((ext_vector_type(4), aligned(4)));
+    if (x + 3 < w) {
+        const f4_t a0 = *(const f4_t *)sp, a1 = *(const f4_t *)(sp + 4);
+        f4_t o; o[0] = a0[0]; o[1] = a0[2]; o[2] = a1[0]; o[3] = a1[2];
+        *(f4_t *)dp = o;
+    } else {
+        for (int j = 0; x + j < w; ++j) dp[j] = sp[2 * j];
+    }
 }
 
 // d = a - b (DoG of one level pair; only the unfused fallback path uses it)
@@ -1279,7 +1290,7 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
         const int w = dv.w[o], hh = dv.h[o];
         const long long pn = (long long)w * hh;
         if (o > 0)
-            hipLaunchKernelGGL(sift_halve_kernel, dim3((w + 255) / 256, hh, n), dim3(256), 0, h->stream,
+            hipLaunchKernelGGL(sift_halve_kernel, dim3((w + 1023) / 1024, hh, n), dim3(256), 0, h->stream,
                                (const float *)(S->d_gauss + dv.goff[o - 1] + (long long)S_NOL * dv.w[o - 1] * dv.h[o - 1]),
                                S->d_gauss + dv.goff[o], dv.gstride, dv.w[o - 1], w, hh);
         for (int i = 1; i < S_NG; ++i)
