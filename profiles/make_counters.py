@@ -68,10 +68,13 @@ def main():
         e["launches_per_step"] = max(1, round(n_l / steps))
         kernels[k] = e
     if stats_csv:
+        tot = defaultdict(lambda: [0.0, 0])              # template instantiations of one kernel are one entry here
         for r in csv.DictReader(open(stats_csv)):
-            k = kname(r["Name"])
-            if k in kernels:
-                kernels[k]["kernel_trace_avg_ns"] = float(r["AverageNs"]); kernels[k]["kernel_trace_calls"] = int(r["Calls"])
+            t = tot[kname(r["Name"])]
+            t[0] += float(r["TotalDurationNs"]); t[1] += int(r["Calls"])
+        for k, (ns, calls) in tot.items():
+            if k in kernels and calls:
+                kernels[k]["kernel_trace_avg_ns"] = ns / calls; kernels[k]["kernel_trace_calls"] = calls
     db = json.load(open(out)) if os.path.exists(out) else {}
     db[key] = {"workload": text,
                "passes": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_* (three separate runs, --pmc only) "

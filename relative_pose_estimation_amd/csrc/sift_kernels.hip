@@ -5,19 +5,22 @@
 // sift.simd.hpp as restated in oracle/sift_oracle.c; every f32 operation keeps the oracle's
 // order (contraction off, deterministic exp/sincos, fixed partial-sum trees), so results
 // compare bit for bit.  Kernel groups (all images of the batch per launch):
-//   upsample  : u8 -> f32, 2x INTER_LINEAR
-//   blur      : fused separable Gaussian per 64 x {64,32} tile (window + row-pass plane in LDS, packed-f32 taps),
-//               reflect-101; an unfused row/column pair remains as the fallback for other tap counts
+//   upsample  : u8 -> f32, 2x INTER_LINEAR in exact integer arithmetic (weights 1/4, 3/4), 4 x 2 outputs per lane
+//   blur      : fused separable Gaussian per 64 x 32 tile (window + row-pass plane in LDS, packed-f32 taps read as
+//               operand pairs by two-offset LDS reads, 16-byte stores), reflect-101; an unfused row/column pair
+//               remains as the fallback for other tap counts
 //   halve     : INTER_NEAREST octave decimation
 //   (DoG)     : never stored: layer l = G[l+1] - G[l] is formed where it is consumed (extrema scan, adjust)
-//   extrema   : tiled 26-neighbour test (rolling LDS layers, separable max/min, DPP) -> 1-bit hit mask + one
-//               counter per (octave, layer, row) band; parallel band scan; wave-per-row emit = raster-ordered seeds
+//   extrema   : tiled 26-neighbour test (rolling LDS layers with halo columns, 3x3x3 max/min from LDS reads) -> 1-bit hit
+//               mask + one counter per (octave, layer, row) band; parallel band scan; wave-per-row emit = raster-ordered seeds
 //   adjust    : one lane per seed: adjustLocalExtrema (contrast / edge tests); survivors appended by integer atomics
-//   orient    : one wave per survivor: 36-bin orientation histogram (8 LDS rounds x 8 lanes keep the per-slot
-//               summation order), peaks -> raw keypoints
+//   orient    : one wave per survivor: 36-bin orientation histogram in 8 interleaved partials per bin (per-slot order
+//               kept in registers by DPP row shifts), Gaussian weights from a per-keypoint table, peaks -> raw keypoints
 //   sort      : response prefilter, bitonic sort of the raw keypoints by KeyPoint_LessThan (one workgroup / image)
 //   finalize  : duplicate removal, retainBest(nfeatures) by radix select, ordered compaction
 //   describe  : one wave per keypoint, 4x4x8 trilinear histogram in 8 interleaved partials, lane = (slot, corner)
+// Kernels whose lanes append through a returning atomic on a per-image counter (adjust, orient) put the image index on
+// the fastest grid axis, so that workgroups in flight together hit different counters.
 #include "rpe_internal.h"
 #include "rpe_devmath.h"
 #include <float.h>
@@ -295,10 +298,11 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
         }
     }
     __syncthreads();
-    // column pass: a wave owns 8-row groups of the tile, a lane one column.  Stores are issue-bound per instruction
-    // (8 dword stores per lane cost a third of the kernel), so inside the image the wave turns its 8 x 64 results through
-    // LDS (the window plane is dead after the row pass; each wave uses its own 2 KB of it, no barrier) and writes them as
-    // two 16-byte stores per lane = four 256-byte rows per instruction.
+    // column pass: a wave owns 8-row groups of the tile, a lane one column.  Inside the image the wave turns its 8 x 64
+    // results through LDS (the window plane is dead after the row pass; each wave uses its own 2 KB of it, no barrier)
+    // and writes them as two 16-byte stores per lane = four 256-byte rows per instruction instead of 8 dword stores
+    // (measured: the same time -- the stores of this kernel cost by the byte, a third of its time -- but fewer
+    // instructions).
     const int lane = tid & 63;
     const int x = x0 + lane;
     const long long ob = (long long)blockIdx.y * dstride;
@@ -391,22 +395,14 @@ __device__ __forceinline__ int s_block_excl_scan(int v, int *s_wave, int &total)
 
 // Pass 1 (tiled, any order): 26-neighbour test of the three inner DoG layers of a 64x32 tile.  The
 // five layers roll through three LDS planes (each DoG value leaves HBM once per tile).  "No
-// neighbour is greater" <=> val >= max of the 3x3x3 block (val itself included), and that max is
-// separable: per lane (= column) the max/min over 3 layers of one row (3 LDS reads per new row),
-// rolled over 3 rows, then across columns with two DPP wave shifts; the tile's halo columns are
-// read by broadcast.  A wave owns 8 consecutive rows; the hit flags of a row are a 64-bit ballot =
-// one mask word, its popcount goes to the row's band counter (integer atomic: deterministic).
+// neighbour is greater" <=> val >= max of the 3x3x3 block (val itself included): per lane (= column)
+// the max/min over 3 layers x 3 columns of one row (9 LDS reads per new row; the planes carry the
+// halo columns), rolled over 3 rows.  A wave owns 8 consecutive rows; the hit flags of a row are a
+// 64-bit ballot = one mask word, its popcount goes to the row's band counter (integer atomic:
+// deterministic).
 #define SX_TW 64
 #define SX_TH 32
 #define SX_P 67
-__device__ __forceinline__ float dpp_wave_shr1(float v)     // lane i <- lane i-1 (lane 0 keeps v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float dpp_wave_shl1(float v)     // lane i <- lane i+1 (lane 63 keeps v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
-}
 __global__ __launch_bounds__(256) void sift_extrema_mask_kernel(const float *__restrict__ gauss, SiftDev dv, const SiftXTile *__restrict__ tiles,
                                                                  unsigned long long *__restrict__ mask, int *__restrict__ band_cnt, int ntiles)
 {
