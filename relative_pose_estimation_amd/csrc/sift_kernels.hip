@@ -185,9 +185,24 @@ __device__ __forceinline__ void lds_pairs(f32x2 *P, unsigned addr, std::integer_
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     (asm_pin(P[Ms]), ...);
 }
-template <int R, int TH>
+// 2x upsampled pixel (x, y) of a u8 image, as sift_upsample_kernel makes it (exact integer form, clamped source indices)
+__device__ __forceinline__ float sift_up_at(const uint8_t *__restrict__ s8, int W, int H, int x, int y)
+{
+    const int t = (x - 1) >> 1, r = (y - 1) >> 1;                       // x odd: columns (t, t+1) weights (3, 1); even: (1, 3)
+    const uint8_t *ra = s8 + (size_t)max(r, 0) * W, *rb = s8 + (size_t)min(r + 1, H - 1) * W;
+    const int ca = max(t, 0), cb = min(t + 1, W - 1);
+    const unsigned wx = (x & 1) ? 3u : 1u, wy = (y & 1) ? 3u : 1u;
+    const unsigned ha = wx * ra[ca] + (4u - wx) * ra[cb], hb = wx * rb[ca] + (4u - wx) * rb[cb];
+    return (float)(wy * ha + (4u - wy) * hb) * 0.0625f;
+}
+
+// UPS: the source level is the 2x upsampled u8 input image itself, formed while the window is loaded (first blur of the
+// pyramid: the upsampled f32 image -- 33 MB per HD image written and read back -- never exists); u8a / u8b = the two
+// image batches of the launch group (image index < na: first batch), W x H their size, w = 2 W, h = 2 H.
+template <int R, int TH, bool UPS>
 __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__restrict__ src, long long sstride, float *__restrict__ dst,
-                                                               long long dstride, int w, int h, int kid, int tcols, int ntiles)
+                                                               long long dstride, int w, int h, int kid, int tcols, int ntiles,
+                                                               const uint8_t *__restrict__ u8a, const uint8_t *__restrict__ u8b, int na, int W, int H)
 {
     // TH = tile height: the LDS footprint (WINH x (SP + 64) floats) decides how many workgroups a CU holds; at R >= 8 a
     // 64-row tile leaves 2 per CU and the kernel waits on its own window loads, a 32-row tile fits 4 (and 6 at R = 5, 6,
@@ -207,6 +222,8 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
     if (ti >= ntiles) return;
     const int x0 = (ti % tcols) * 64, y0 = (ti / tcols) * TH;
     const float *s = src + (long long)blockIdx.y * sstride;
+    const uint8_t *s8 = nullptr;
+    if constexpr (UPS) s8 = (int)blockIdx.y < na ? u8a + (size_t)blockIdx.y * W * H : u8b + (size_t)((int)blockIdx.y - na) * W * H;
     if (x0 >= HAL && x0 + 64 + HAL <= w && y0 >= R && y0 + TH + R <= h) {
         // Interior tile (91 % of the tiles of a 3840 x 2160 octave): no reflection anywhere, so the window is fetched as
         // global_load_dwordx4 chunks (4-byte aligned is all the hardware asks of a multi-dword load).  A lane keeps its
@@ -224,12 +241,38 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
         float *d = s_src + lr * SP + 4 * c4 - PADF;
         constexpr int LASTQ = NQ - 1, LAST_FULL = RPP * NQ <= WINH;
         const int lrl = LAST_FULL ? lr : min(lr, WINH - 1 - RPP * LASTQ);   // row of the last pass, clamped into the window
+        if constexpr (UPS) {
+            // chunk = upsampled pixels x = 4t .. 4t+3 of row y: source columns 2t-1 .. 2t+2 of rows r, r+1 (r = (y-1) >> 1),
+            // horizontal weights (1,3) (3,1) (1,3) (3,1), vertical (3,1) for odd y and (1,3) for even y; integers, exact
+            const int tq = (x0 - HAL + 4 * c4) >> 2;
+            const int cm = 2 * tq - 1, cp = min(2 * tq + 2, W - 1);              // interior tile: cm >= 0
+            unsigned bytes[NQ][2][4];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const float *aq = q < LASTQ ? a + (size_t)(RPP * q) * w : a + (size_t)(RPP * q + lrl - lr) * w;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stage[q]) : "v"(aq) : "memory");   // all in flight together
+            for (int q = 0; q < NQ; ++q) {
+                const int wy = y0 - R + (q < LASTQ ? lr + RPP * q : lrl + RPP * q);
+                const int r = (wy - 1) >> 1;
+                const uint8_t *ra = s8 + (size_t)max(r, 0) * W, *rb = s8 + (size_t)min(r + 1, H - 1) * W;
+                bytes[q][0][0] = ra[cm]; bytes[q][0][1] = ra[2 * tq]; bytes[q][0][2] = ra[2 * tq + 1]; bytes[q][0][3] = ra[cp];
+                bytes[q][1][0] = rb[cm]; bytes[q][1][1] = rb[2 * tq]; bytes[q][1][2] = rb[2 * tq + 1]; bytes[q][1][3] = rb[cp];
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int wy = y0 - R + (q < LASTQ ? lr + RPP * q : lrl + RPP * q);
+                const unsigned wa = (wy & 1) ? 3u : 1u, wb = 4u - wa;
+                const unsigned *a4 = bytes[q][0], *b4 = bytes[q][1];
+                const unsigned ha[4] = {a4[0] + 3 * a4[1], 3 * a4[1] + a4[2], a4[1] + 3 * a4[2], 3 * a4[2] + a4[3]};
+                const unsigned hb[4] = {b4[0] + 3 * b4[1], 3 * b4[1] + b4[2], b4[1] + 3 * b4[2], 3 * b4[2] + b4[3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) stage[q][e] = (float)(wa * ha[e] + wb * hb[e]) * 0.0625f;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float *aq = q < LASTQ ? a + (size_t)(RPP * q) * w : a + (size_t)(RPP * q + lrl - lr) * w;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stage[q]) : "v"(aq) : "memory");   // all in flight together
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             asm volatile("" : "+v"(stage[q]));
@@ -251,7 +294,7 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
             int yy = min(max(y0 + r - R, -R), h - 1 + R), xx = min(max(x0 + c - R, -R), w - 1 + R);
             yy = yy < 0 ? -yy : yy; yy = yy >= h ? 2 * h - 2 - yy : yy;
             xx = xx < 0 ? -xx : xx; xx = xx >= w ? 2 * w - 2 - xx : xx;
-            stage[q] = s[(size_t)yy * w + xx];
+            if constexpr (UPS) stage[q] = sift_up_at(s8, W, H, xx, yy); else stage[q] = s[(size_t)yy * w + xx];
         }
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
@@ -262,7 +305,8 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
     } else {
         for (int i = tid; i < WINH * WIN; i += 256) {
             const int r = i / WIN, c = i - r * WIN;
-            s_src[r * SP + c] = s[(size_t)s_refl(y0 + r - R, h) * w + s_refl(x0 + c - R, w)];
+            const int yy = s_refl(y0 + r - R, h), xx = s_refl(x0 + c - R, w);
+            if constexpr (UPS) s_src[r * SP + c] = sift_up_at(s8, W, H, xx, yy); else s_src[r * SP + c] = s[(size_t)yy * w + xx];
         }
     }
     float k[KS];
@@ -1200,7 +1244,12 @@ int rpe_sift_create(rpe_handle *h)
     if (!xt.empty()) SCHK(hipMemcpy(S->d_xtiles, xt.data(), sizeof(SiftXTile) * xt.size(), hipMemcpyHostToDevice));
     SCHK(hipMalloc(&S->d_xmask, sizeof(unsigned long long) * NI * dv.bmstride));
     SCHK(hipMalloc(&S->d_gauss, sizeof(float) * NI * dv.gstride));
-    SCHK(hipMalloc(&S->d_tmp, sizeof(float) * NI * dv.tstride * 2));
+    {   // scratch of the unfused fallbacks (upsampled image + row-pass image, 66 MB per HD image): only when a tap count has
+        // no fused instantiation, which the reference's SIFT parameters (sigma 1.6, 3 layers: radii 5 5 6 8 10 13) never produce
+        bool need_tmp = (ks[0] >> 1) != 5;
+        for (int i = 0; i < S_NG; ++i) { const int r = ks[i] >> 1; if (r != 5 && r != 6 && r != 8 && r != 10 && r != 13) need_tmp = true; }
+        if (need_tmp) SCHK(hipMalloc(&S->d_tmp, sizeof(float) * NI * dv.tstride * 2));
+    }
     SCHK(hipMalloc(&S->d_band_cnt, sizeof(int) * NI * dv.nbands));
     SCHK(hipMalloc(&S->d_band_off, sizeof(int) * NI * dv.nbands));
     SCHK(hipMalloc(&S->d_seeds, sizeof(unsigned) * NI * dv.seed_cap));
@@ -1229,14 +1278,15 @@ void rpe_sift_destroy(rpe_handle *h)
     h->sift = nullptr;
 }
 
-template <int R>
+template <int R, bool UPS = false>
 static void sift_blur_launch(rpe_handle *h, const float *src, long long sstride, float *dst, long long dstride, float *dog,
-                             long long dogstride, int w, int hh, int kid, int n_img)
+                             long long dogstride, int w, int hh, int kid, int n_img, const uint8_t *u8a = nullptr,
+                             const uint8_t *u8b = nullptr, int na = 0)
 {
     constexpr int TH = 32;
     const int tcols = (w + 63) / 64, ntiles = tcols * ((hh + TH - 1) / TH);
-    hipLaunchKernelGGL((sift_blur_fused_kernel<R, TH>), dim3((ntiles + 7) / 8 * 8, n_img), dim3(256), 0, h->stream, src, sstride, dst, dstride,
-                       w, hh, kid, tcols, ntiles);
+    hipLaunchKernelGGL((sift_blur_fused_kernel<R, TH, UPS>), dim3((ntiles + 7) / 8 * 8, n_img), dim3(256), 0, h->stream, src, sstride, dst, dstride,
+                       w, hh, kid, tcols, ntiles, u8a, u8b, na, w / 2, hh / 2);
     if (dog)      // DoG planes are not stored by the product path (layers are formed where they are consumed); kept for callers that ask
         hipLaunchKernelGGL(sift_sub_kernel, dim3((unsigned)(((long long)w * hh + 255) / 256), 1, n_img), dim3(256), 0, h->stream,
                            (const float *)dst, dstride, src, sstride, dog, dogstride, (long long)w * hh);
@@ -1272,15 +1322,20 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
     // scan, SELECT = adjustLocalExtrema, HARRIS = orientation histograms, KEYPOINTS = prefilter + sort + retainBest,
     // DESCRIBE = descriptors; NMS / ANGLE / BLUR are empty
     MARK(h, RPE_STAGE_PYRAMID);
-    // 1. upsample + initial blur -> gaussian[0][0]
-    for (int part = 0; part < 2; ++part) {
-        const uint8_t *src = part ? d_b : d_a; const int cnt = part ? nb : na, first = part ? na : 0;
-        if (!cnt) continue;
-        hipLaunchKernelGGL(sift_upsample_kernel, dim3((bw / 4 + 256) / 256, H + 1, cnt), dim3(256), 0, h->stream, src, W, H, img,
-                           S->d_tmp + (long long)first * dv.tstride, dv.tstride);
-    }
+    // 1. upsample + initial blur -> gaussian[0][0]: one kernel (the upsampled image is formed in the blur's window loader);
+    //    the separate upsample kernel only feeds the unfused fallback for an unexpected tap count
     const int n = na + nb;
-    sift_blur(h, S->d_tmp, dv.tstride, S->d_gauss + dv.goff[0], dv.gstride, nullptr, 0, bw, bh, 0, n);
+    if ((S->ks[0] >> 1) == 5) {
+        sift_blur_launch<5, true>(h, nullptr, 0, S->d_gauss + dv.goff[0], dv.gstride, nullptr, 0, bw, bh, 0, n, d_a, d_b, na);
+    } else {
+        for (int part = 0; part < 2; ++part) {
+            const uint8_t *src = part ? d_b : d_a; const int cnt = part ? nb : na, first = part ? na : 0;
+            if (!cnt) continue;
+            hipLaunchKernelGGL(sift_upsample_kernel, dim3((bw / 4 + 256) / 256, H + 1, cnt), dim3(256), 0, h->stream, src, W, H, img,
+                               S->d_tmp + (long long)first * dv.tstride, dv.tstride);
+        }
+        sift_blur(h, S->d_tmp, dv.tstride, S->d_gauss + dv.goff[0], dv.gstride, nullptr, 0, bw, bh, 0, n);
+    }
     // 2. gaussian pyramid + DoG
     for (int o = 0; o < dv.noct; ++o) {
         const int w = dv.w[o], hh = dv.h[o];
