@@ -199,10 +199,13 @@ __device__ __forceinline__ float sift_up_at(const uint8_t *__restrict__ s8, int 
 // UPS: the source level is the 2x upsampled u8 input image itself, formed while the window is loaded (first blur of the
 // pyramid: the upsampled f32 image -- 33 MB per HD image written and read back -- never exists); u8a / u8b = the two
 // image batches of the launch group (image index < na: first batch), W x H their size, w = 2 W, h = 2 H.
+// dec (optional): level 0 of the next octave = this level at even x, even y (INTER_NEAREST halving), w2 x h2, written from
+// the same registers (the separate decimation pass read the level back through 64-byte lines it used half of).
 template <int R, int TH, bool UPS>
 __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__restrict__ src, long long sstride, float *__restrict__ dst,
                                                                long long dstride, int w, int h, int kid, int tcols, int ntiles,
-                                                               const uint8_t *__restrict__ u8a, const uint8_t *__restrict__ u8b, int na, int W, int H)
+                                                               const uint8_t *__restrict__ u8a, const uint8_t *__restrict__ u8b, int na, int W, int H,
+                                                               float *__restrict__ dec, int w2, int h2)
 {
     // TH = tile height: the LDS footprint (WINH x (SP + 64) floats) decides how many workgroups a CU holds; at R >= 8 a
     // 64-row tile leaves 2 per CU and the kernel waits on its own window loads, a 32-row tile fits 4 (and 6 at R = 5, 6,
@@ -374,7 +377,11 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int yl = j + 4 * hh;
-                    if (yl < rows_left && x < w) (pd + (size_t)yl * w)[lane] = hh ? acc.y : acc.x;
+                    if (yl < rows_left && x < w) {
+                        (pd + (size_t)yl * w)[lane] = hh ? acc.y : acc.x;
+                        if (dec && !((yb + yl) & 1) && !(x & 1) && ((yb + yl) >> 1) < h2 && (x >> 1) < w2)
+                            dec[(long long)blockIdx.y * dstride + (size_t)((yb + yl) >> 1) * w2 + (x >> 1)] = hh ? acc.y : acc.x;
+                    }
                 }
             }
         }
@@ -386,6 +393,11 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
                 const f4_t v = *(const f4_t *)(so + (4 * t + rr) * 64 + c4);
                 // scalar row base + 32-bit lane offset
                 asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(voff), "v"(v), "s"(pd + (size_t)(4 * t) * w) : "memory");
+                if (dec && !(rr & 1)) {                         // rows yb + 4t + rr even (yb is a multiple of 8), columns c4, c4 + 2
+                    const int y2 = (yb + 4 * t + rr) >> 1, x2 = (x0 + c4) >> 1;
+                    float *q = dec + (long long)blockIdx.y * dstride + (size_t)y2 * w2 + x2;
+                    if (y2 < h2) { if (x2 < w2) q[0] = v[0]; if (x2 + 1 < w2) q[1] = v[2]; }
+                }
             }
         }
     }
@@ -1281,27 +1293,28 @@ void rpe_sift_destroy(rpe_handle *h)
 template <int R, bool UPS = false>
 static void sift_blur_launch(rpe_handle *h, const float *src, long long sstride, float *dst, long long dstride, float *dog,
                              long long dogstride, int w, int hh, int kid, int n_img, const uint8_t *u8a = nullptr,
-                             const uint8_t *u8b = nullptr, int na = 0)
+                             const uint8_t *u8b = nullptr, int na = 0, float *dec = nullptr, int w2 = 0, int h2 = 0)
 {
     constexpr int TH = 32;
     const int tcols = (w + 63) / 64, ntiles = tcols * ((hh + TH - 1) / TH);
     hipLaunchKernelGGL((sift_blur_fused_kernel<R, TH, UPS>), dim3((ntiles + 7) / 8 * 8, n_img), dim3(256), 0, h->stream, src, sstride, dst, dstride,
-                       w, hh, kid, tcols, ntiles, u8a, u8b, na, w / 2, hh / 2);
+                       w, hh, kid, tcols, ntiles, u8a, u8b, na, w / 2, hh / 2, dec, w2, h2);
     if (dog)      // DoG planes are not stored by the product path (layers are formed where they are consumed); kept for callers that ask
         hipLaunchKernelGGL(sift_sub_kernel, dim3((unsigned)(((long long)w * hh + 255) / 256), 1, n_img), dim3(256), 0, h->stream,
                            (const float *)dst, dstride, src, sstride, dog, dogstride, (long long)w * hh);
 }
 
-// G[dst] = gauss(kid) * G[src]; dog (optional) = G[dst] - G[src]
-static void sift_blur(rpe_handle *h, const float *src, long long sstride, float *dst, long long dstride, float *dog, long long dogstride,
-                      int w, int hh, int kid, int n_img)
+// G[dst] = gauss(kid) * G[src]; dog (optional) = G[dst] - G[src]; dec (optional, same per-image stride as dst) = dst at even
+// x, even y.  Returns true when dec was written (fused instantiations only; the caller runs sift_halve_kernel otherwise).
+static bool sift_blur(rpe_handle *h, const float *src, long long sstride, float *dst, long long dstride, float *dog, long long dogstride,
+                      int w, int hh, int kid, int n_img, float *dec = nullptr, int w2 = 0, int h2 = 0)
 {
     switch (h->sift->ks[kid] >> 1) {
-    case 5:  sift_blur_launch<5>(h, src, sstride, dst, dstride, dog, dogstride, w, hh, kid, n_img); break;
-    case 6:  sift_blur_launch<6>(h, src, sstride, dst, dstride, dog, dogstride, w, hh, kid, n_img); break;
-    case 8:  sift_blur_launch<8>(h, src, sstride, dst, dstride, dog, dogstride, w, hh, kid, n_img); break;
-    case 10: sift_blur_launch<10>(h, src, sstride, dst, dstride, dog, dogstride, w, hh, kid, n_img); break;
-    case 13: sift_blur_launch<13>(h, src, sstride, dst, dstride, dog, dogstride, w, hh, kid, n_img); break;
+    case 5:  sift_blur_launch<5>(h, src, sstride, dst, dstride, dog, dogstride, w, hh, kid, n_img, nullptr, nullptr, 0, dec, w2, h2); return dec != nullptr;
+    case 6:  sift_blur_launch<6>(h, src, sstride, dst, dstride, dog, dogstride, w, hh, kid, n_img, nullptr, nullptr, 0, dec, w2, h2); return dec != nullptr;
+    case 8:  sift_blur_launch<8>(h, src, sstride, dst, dstride, dog, dogstride, w, hh, kid, n_img, nullptr, nullptr, 0, dec, w2, h2); return dec != nullptr;
+    case 10: sift_blur_launch<10>(h, src, sstride, dst, dstride, dog, dogstride, w, hh, kid, n_img, nullptr, nullptr, 0, dec, w2, h2); return dec != nullptr;
+    case 13: sift_blur_launch<13>(h, src, sstride, dst, dstride, dog, dogstride, w, hh, kid, n_img, nullptr, nullptr, 0, dec, w2, h2); return dec != nullptr;
     default: {      // any other width: unfused two-pass path
         float *tmp = h->sift->d_tmp + (long long)h->n_img_cap * h->sift->dv.tstride;
         hipLaunchKernelGGL(sift_blur_row_kernel, dim3((w + 255) / 256, hh, n_img), dim3(256), 0, h->stream, src, sstride, tmp, h->sift->dv.tstride, w, hh, kid);
@@ -1309,6 +1322,7 @@ static void sift_blur(rpe_handle *h, const float *src, long long sstride, float 
         if (dog) hipLaunchKernelGGL(sift_sub_kernel, dim3((unsigned)(((long long)w * hh + 255) / 256), 1, n_img), dim3(256), 0, h->stream,
                                     (const float *)dst, dstride, src, sstride, dog, dogstride, (long long)w * hh);
     } }
+    return false;
 }
 
 // d_imgs: n_img tightly packed u8 images already resident (d_a followed by d_b as in the ORB path)
@@ -1336,17 +1350,23 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
         }
         sift_blur(h, S->d_tmp, dv.tstride, S->d_gauss + dv.goff[0], dv.gstride, nullptr, 0, bw, bh, 0, n);
     }
-    // 2. gaussian pyramid + DoG
+    // 2. gaussian pyramid; level 0 of octave o + 1 (= level S_NOL of octave o, halved) is written by the blur that makes that level
+    bool have_l0 = true;                                   // octave 0: made by step 1
     for (int o = 0; o < dv.noct; ++o) {
         const int w = dv.w[o], hh = dv.h[o];
         const long long pn = (long long)w * hh;
-        if (o > 0)
+        if (!have_l0)
             hipLaunchKernelGGL(sift_halve_kernel, dim3((w + 1023) / 1024, hh, n), dim3(256), 0, h->stream,
                                (const float *)(S->d_gauss + dv.goff[o - 1] + (long long)S_NOL * dv.w[o - 1] * dv.h[o - 1]),
                                S->d_gauss + dv.goff[o], dv.gstride, dv.w[o - 1], w, hh);
-        for (int i = 1; i < S_NG; ++i)
-            sift_blur(h, S->d_gauss + dv.goff[o] + (i - 1) * pn, dv.gstride, S->d_gauss + dv.goff[o] + i * pn, dv.gstride,
-                      nullptr, 0, w, hh, i, n);
+        have_l0 = false;
+        for (int i = 1; i < S_NG; ++i) {
+            const bool last = o + 1 >= dv.noct;
+            float *dec = i == S_NOL && !last ? S->d_gauss + dv.goff[o + 1] : nullptr;
+            const bool wrote = sift_blur(h, S->d_gauss + dv.goff[o] + (i - 1) * pn, dv.gstride, S->d_gauss + dv.goff[o] + i * pn, dv.gstride,
+                                         nullptr, 0, w, hh, i, n, dec, last ? 0 : dv.w[o + 1], last ? 0 : dv.h[o + 1]);
+            if (i == S_NOL) have_l0 = wrote;
+        }
     }
     // 3. seeds (count, scan, emit)
     MARK(h, RPE_STAGE_FAST);
