@@ -471,7 +471,8 @@ __global__ __launch_bounds__(256) void sift_extrema_mask_kernel(const float *__r
     const int img = blockIdx.y, o = t.o, w = dv.w[o], h = dv.h[o], x0 = t.x0, y0 = t.y0;
     const long long n = (long long)w * h;
     const float *d = gauss + (long long)img * dv.gstride + dv.goff[o];     // Gaussian levels; DoG l = G[l+1] - G[l]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index in a scalar register: row numbers, mask and counter addresses stay scalar
     constexpr int NEL = (SX_TH + 2) * (SX_TW + 2), NLD = (NEL + 255) / 256;
     float stage[NLD], prevg[NLD];
     // element q of this lane: clamped source offset inside a level (32-bit, the level base stays scalar) and LDS offset;
