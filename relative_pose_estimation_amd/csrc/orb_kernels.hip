@@ -101,7 +101,7 @@ __device__ __forceinline__ bool xcd_image_block(int nb, int n_img, int &img, int
 static inline unsigned xcd_image_grid(int nb, int n_img) { return (unsigned)(8 * ((n_img + 7) / 8) * nb); }
 
 // ---------------------------------------------------------------- pyramid
-// Workgroup = 128 x PYR_TH destination tile of level l.  The source footprint in level l-1
+// Workgroup = PYR_TW x PYR_TH destination tile of level l.  The source footprint in level l-1
 // (<= PYR_ROWS rows x 152 bytes, bounds derived arithmetically so the loads do not depend on
 // the coefficient tables; checked on the host) is staged in LDS with aligned 16-byte loads, all of
 // them in flight before the first LDS store -- 6.9 KB per workgroup at PYR_TH = 32.

@@ -156,7 +156,7 @@ static int build_tables(rpe_handle *h)
         lin_coeffs(S.w, D.w, xo, xa);
         lin_coeffs(S.h, D.h, yo, ya);
     }
-    // resize tiles (128 x PYR_TH destination pixels) with the origin of their source window, levels 1..11
+    // resize tiles (PYR_TW x PYR_TH destination pixels) with the origin of their source window, levels 1..11
     {
         std::vector<RpePyrTile> pt;
         for (int l = 1; l < RPE_NLEVELS; ++l) {
@@ -170,7 +170,7 @@ static int build_tables(rpe_handle *h)
         DM(h, h->d_pyr_tiles, pt.size() ? pt.size() : 1);
         if (!pt.empty()) HIPCHK(h, hipMemcpy(h->d_pyr_tiles, pt.data(), pt.size() * sizeof(RpePyrTile), hipMemcpyHostToDevice));
     }
-    // the resize kernel stages a fixed PYR_ROWS-row x 176-byte source footprint per 128 x PYR_TH tile (origin 16-B aligned),
+    // the resize kernel stages a fixed PYR_ROWS-row x (4 PYR_DW)-byte source footprint per PYR_TW x PYR_TH tile (origin 16-B aligned),
     // anchored at floor(scale * tile origin); verify the tables fit it for every tile
     for (int l = 1; l < RPE_NLEVELS; ++l) {
         const RpeLevel &S = L.lv[l - 1], &D = L.lv[l];

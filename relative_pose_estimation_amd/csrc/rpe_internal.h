@@ -81,22 +81,24 @@ RPE_WAVE_SCAN(wave_inclusive_min, RPE_OP_MIN, 0x7FFFFFFF)
 __device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_inclusive_sum(v), 63); }
 
 struct RpeTile { short level, tx, ty, pad; };
-// 128 x PYR_TH destination tile of the resize kernel: destination origin and origin of its source window in the level below
+// PYR_TW x PYR_TH destination tile of the resize kernel: destination origin and origin of its source window in the level below
 struct RpePyrTile { short x0, y0, a0, sy0; };
-// destination tile 128 x PYR_TH; a lane computes 4 columns x 2 groups of 8 rows.  32 rows = ONE wave per tile and 23 tile
-// windows (6.9 KB each) per CU: 1.89 -> 1.68 ms against 64 rows / two waves / 12 windows (the phases of a tile overlap
-// only through other workgroups, so many small independent ones beat few large ones)
+// destination tile 256 x 16, ONE wave per tile: a lane computes 4 columns x 2 groups of 8 rows.  Small one-wave tiles put
+// many independent windows (7.7 KB each) on a CU -- the phases of a tile overlap only through other workgroups: 64-row
+// tiles of two waves 1.89 ms, 128 x 32 of one wave 1.68 -- and the longer the contiguous rows the better the mixed read /
+// write stream runs: 64-wide 1.82, 128-wide 1.67, 256 x 16 1.64 ms (partial tiles at the right edge idle lanes, which a
+// memory-bound kernel does not feel)
 #ifndef PYR_TH
-#define PYR_TH 32
+#define PYR_TH 16
 #endif
 #ifndef PYR_TW
-#define PYR_TW 128                   // destination tile width (64-wide tiles, also one wave each, measured 1.67 -> 1.82 ms)
+#define PYR_TW 256                   // destination tile width
 #endif
-#define PYR_DW (PYR_TW == 128 ? 44 : 24)    // window row in dwords: 176 B = 11 x 16-B loads (origin aligned down to 16 B), 96 B for 64-wide tiles
+#define PYR_DW (PYR_TW == 256 ? 84 : PYR_TW == 128 ? 44 : 24)   // window row in dwords: 336 B = 21 x 16-B loads (origin aligned down to 16 B); 176 B / 96 B for 128- / 64-wide tiles
 #ifndef PYR_THREADS
-#define PYR_THREADS (PYR_TH * 2)     // 32 column groups x PYR_TH / 16 row-group pairs
+#define PYR_THREADS (PYR_TW / 4 * PYR_TH / 16)   // PYR_TW / 4 column groups x PYR_TH / 16 row-group pairs
 #endif
-#define PYR_ROWS (PYR_TH == 64 ? 74 : 39)   // source rows staged per tile (checked against the tables at create time)
+#define PYR_ROWS (PYR_TH == 64 ? 74 : PYR_TH == 16 ? 23 : 39)   // source rows staged per tile (checked against the tables at create time)
 
 // per-pair RANSAC state in HBM
 struct RpeRansacState {
