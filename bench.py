@@ -472,7 +472,13 @@ def main():
         a3 = argparse.Namespace(**vars(args))
         a3.config, a3.steps, a3.warmup, a3.unique, a3.cpu_sample, a3.data_cache = 3, 2, 1, 16, 16, ""
         m3, s3 = resolve(a3)
-        extras.append(("config3_128pairs", a3, m3, s3, generate(a3, m3, 0, 1, workers)))
+        d3 = generate(a3, m3, 0, 1, workers)
+        extras.append(("config3_128pairs", a3, m3, s3, d3))
+        # the same 128 HD pairs as three launch groups on three handles / HIP streams (43 + 43 + 42 pairs): the large SIFT
+        # kernels of one group overlap those of another where they are bound by different resources (about -6 %)
+        a3s = argparse.Namespace(**vars(a3))
+        a3s.streams, a3s.no_cpu_baseline, a3s.no_calibrate = 3, True, True
+        extras.append(("config3_three_streams", a3s, m3, s3, d3))
         ast = argparse.Namespace(**vars(args))
         ast.stream, ast.cpu_sample, ast.data_cache = True, 256, ""
         extras.append(("stream", ast, "ORB", ast.batch, generate(ast, "ORB", 0, 1, workers)))
