@@ -6,18 +6,29 @@
  *   truncation to max_matches (:150-151).
  *
  * crossCheck semantics follow OpenCV core/batch_distance.cpp
- * (batchDistance(..., crosscheck=true)): every train row elects its nearest
- * query (strict '<' scanning queries ascending => lowest query index on
- * ties); every query keeps, among the trains that elected it, the one with
- * the smallest distance (strict '<' scanning trains ascending => lowest train
- * index on ties); matches are emitted in ascending query index.  Python's
- * sorted() is stable, so the final order is (distance, queryIdx).
+ * (batchDistance(..., crosscheck=true)) as of the 4.5.x fix that every
+ * opencv-python >= 4.8 (requirements.txt:1) carries -- two passes:
+ *   batchDistance(src2, src1, tdist, tidx)   tidx[j] = nearest query of train j
+ *   batchDistance(src1, src2, sdist, sidx)   sidx[i] = nearest train of query i
+ * (K = 1, strict '<' while scanning ascending => lowest index on ties); then
+ *   for j ascending: i = tidx[j]; if (tdist[j] < dist[i]) { dist[i] = tdist[j]; nidx[i] = j; }
+ *   for i:           if (tidx[sidx[i]] != i) nidx[i] = -1;
+ * i.e. a query keeps its best elector, and the match survives only if the
+ * query's own nearest train elected it: strict mutual nearest neighbours with
+ * lowest-index tie-breaks.  (If sidx[i] elected i, its distance is the row
+ * minimum and it is the lowest such train, so the surviving match is always
+ * (i, sidx[i]).)  Rounds 1-2 restated the older one-pass rule (electors only,
+ * a superset); experiment knob 2 = 1 brings it back.  Matches are emitted in
+ * ascending query index.  Python's sorted() is stable, so the final order is
+ * (distance, queryIdx).
  */
 #include "oracle.h"
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include <limits.h>
+
+int orc_debug_get_variant(int key);    /* orb_oracle.c */
 
 static int hamming32(const uint8_t *a, const uint8_t *b)
 {
@@ -32,6 +43,7 @@ int orc_match_hamming(const uint8_t *d1, int n1, const uint8_t *d2, int n2,
     if (n1 <= 0 || n2 <= 0) return 0;
     int *best_d = (int *)malloc(sizeof(int) * (size_t)n1);
     int *best_t = (int *)malloc(sizeof(int) * (size_t)n1);
+    int *elect = (int *)malloc(sizeof(int) * (size_t)n2);       /* tidx */
     for (int i = 0; i < n1; ++i) { best_d[i] = INT_MAX; best_t[i] = -1; }
     for (int j = 0; j < n2; ++j) {
         int bi = -1, bd = INT_MAX;
@@ -39,8 +51,19 @@ int orc_match_hamming(const uint8_t *d1, int n1, const uint8_t *d2, int n2,
             int d = hamming32(d1 + 32 * (size_t)i, d2 + 32 * (size_t)j);
             if (d < bd) { bd = d; bi = i; }
         }
+        elect[j] = bi;
         if (bd < best_d[bi]) { best_d[bi] = bd; best_t[bi] = j; }
     }
+    if (orc_debug_get_variant(2) == 0)
+        for (int i = 0; i < n1; ++i) {                          /* sidx[i], then tidx[sidx[i]] == i */
+            int bj = -1, bd = INT_MAX;
+            for (int j = 0; j < n2; ++j) {
+                int d = hamming32(d1 + 32 * (size_t)i, d2 + 32 * (size_t)j);
+                if (d < bd) { bd = d; bj = j; }
+            }
+            if (elect[bj] != i) best_t[i] = -1;
+        }
+    free(elect);
     /* stable sort by distance == counting sort over 0..256 in ascending query index */
     int n = 0;
     int lim = max_matches >= 0 ? max_matches : INT_MAX;
@@ -70,6 +93,7 @@ int orc_match_l2(const float *d1, int n1, const float *d2, int n2, int dim,
     if (n1 <= 0 || n2 <= 0) return 0;
     float *best_d = (float *)malloc(sizeof(float) * (size_t)n1);
     int *best_t = (int *)malloc(sizeof(int) * (size_t)n1);
+    int *elect = (int *)malloc(sizeof(int) * (size_t)n2);       /* tidx */
     for (int i = 0; i < n1; ++i) { best_d[i] = INFINITY; best_t[i] = -1; }
     for (int j = 0; j < n2; ++j) {
         int bi = -1; float bd = INFINITY;
@@ -80,8 +104,22 @@ int orc_match_l2(const float *d1, int n1, const float *d2, int n2, int dim,
             float d = sqrtf(s);
             if (d < bd) { bd = d; bi = i; }
         }
+        elect[j] = bi;
         if (bi >= 0 && bd < best_d[bi]) { best_d[bi] = bd; best_t[bi] = j; }
     }
+    if (orc_debug_get_variant(2) == 0)
+        for (int i = 0; i < n1; ++i) {                          /* sidx[i], then tidx[sidx[i]] == i */
+            int bj = -1; float bd = INFINITY;
+            for (int j = 0; j < n2; ++j) {
+                const float *a = d1 + (size_t)dim * i, *b = d2 + (size_t)dim * j;
+                float s = 0.f;
+                for (int k = 0; k < dim; ++k) { float df = a[k] - b[k]; s += df * df; }
+                float d = sqrtf(s);
+                if (d < bd) { bd = d; bj = j; }
+            }
+            if (bj < 0 || elect[bj] != i) best_t[i] = -1;
+        }
+    free(elect);
     l2m *m = (l2m *)malloc(sizeof(l2m) * (size_t)n1);
     int n = 0;
     for (int i = 0; i < n1; ++i) if (best_t[i] >= 0) { m[n].d = best_d[i]; m[n].q = i; m[n].t = best_t[i]; ++n; }

@@ -38,9 +38,13 @@ static int cv_round(double v) { return (int)lrint(v); }
  * restatement had to guess.  Key 0: Gaussian taps (0 = [18,34,49,55,...] = cvRound(256 g_i), sum 257, the
  * sepFilter2D fixed-point route ORB's in-place blur of a pyramid sub-matrix takes; 1 = [18,34,48,56,...],
  * the sum-256 set of round 1).  Key 1: keypoint order inside a level (0 = raster; 1 = Harris response
- * descending, raster on ties; 2 = reverse raster).  Defaults are what the HIP path implements. */
+ * descending, raster on ties; 2 = reverse raster; 3 = cv2's own order: both retainBest calls through the real
+ * std::nth_element + std::partition, retain_best.cpp).  Key 2: crossCheck rule of the matcher (0 = strict mutual, cv2 >= 4.5.x;
+ * 1 = electors only, the one-pass rule of older OpenCV that rounds 1-2 restated; match_oracle.c).  Defaults are what the HIP path implements. */
 static int g_variant[4] = {0, 0, 0, 0};
+int orc_retain_best(const float *resp, int32_t *ids, int n, int n_points);   /* retain_best.cpp */
 void orc_debug_set_variant(int key, int val) { if (key >= 0 && key < 4) g_variant[key] = val; }
+int orc_debug_get_variant(int key) { return key >= 0 && key < 4 ? g_variant[key] : 0; }
 
 /* orb.cpp: layer scale (float)pow(scaleFactor, level), size cvRound(cols/scale);
  * per-level feature quota (geometric series, remainder to the last level). */
@@ -166,8 +170,36 @@ void orc_orb_nms_map(const uint8_t *score, int w, int h, uint8_t *nms)
 static const int GK_TAB[2][7] = {{18, 34, 49, 55, 49, 34, 18}, {18, 34, 48, 56, 48, 34, 18}};
 static int refl(int p, int n) { if (p < 0) p = -p; if (p >= n) p = 2 * n - 2 - p; return p; }
 
+/* experiment (knob 0 = 2): sepFilter2D's float route -- f32 kernel = (float)(exp(-x^2 / 8) / sum), row pass accumulates
+ * k = 0..6 in f32, column pass centre first then the symmetric pairs, cvRound + saturate */
+static void blur_level_float(const uint8_t *src, int w, int h, uint8_t *dst)
+{
+    float g[7];
+    {
+        double v[7], sum = 0.;
+        for (int i = 0; i < 7; ++i) { double x = (double)(i - 3); v[i] = exp(-0.125 * x * x); sum += v[i]; }
+        for (int i = 0; i < 7; ++i) g[i] = (float)(v[i] / sum);
+    }
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)w * h);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            float s = g[0] * (float)src[(size_t)y * w + refl(x - 3, w)];
+            for (int k = 1; k < 7; ++k) s += g[k] * (float)src[(size_t)y * w + refl(x + k - 3, w)];
+            tmp[(size_t)y * w + x] = s;
+        }
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            float s = g[3] * tmp[(size_t)y * w + x];
+            for (int k = 1; k <= 3; ++k) s += g[3 + k] * (tmp[(size_t)refl(y + k, h) * w + x] + tmp[(size_t)refl(y - k, h) * w + x]);
+            long r = lrintf(s);
+            dst[(size_t)y * w + x] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+        }
+    free(tmp);
+}
+
 void orc_orb_blur_level(const uint8_t *src, int w, int h, uint8_t *dst)
 {
+    if (g_variant[0] == 2) { blur_level_float(src, w, h, dst); return; }
     const int *GK = GK_TAB[g_variant[0] & 1];
     uint16_t *tmp = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)w * h);
     for (int y = 0; y < h; ++y)
@@ -331,6 +363,33 @@ int orc_orb_detect_and_compute_ex(const uint8_t *img, int W, int H, int nfeature
         uint8_t *sm = smap + L.offset[l], *nm = nmap + L.offset[l];
         orc_orb_fast_score_map(lv, w, h, fast_threshold, sm);
         orc_orb_nms_map(sm, w, h, nm);
+        if (g_variant[1] == 3) {
+            /* cv2's own keypoint order: FAST's raster emission -> retainBest(2q) on the FAST score -> Harris ->
+             * retainBest(q), both through libstdc++'s std::nth_element + std::partition (retain_best.cpp) */
+            int total0 = 0;
+            for (int y = EDGE; y < h - EDGE; ++y) for (int x = EDGE; x < w - EDGE; ++x) if (nm[(size_t)y * w + x]) ++total0;
+            float *rs = (float *)malloc(sizeof(float) * (size_t)(total0 + 1));
+            int32_t *id = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total0 + 1));
+            int n0 = 0;
+            for (int y = EDGE; y < h - EDGE; ++y) for (int x = EDGE; x < w - EDGE; ++x) {
+                int v = nm[(size_t)y * w + x];
+                if (v) { rs[n0] = (float)v; id[n0] = y * w + x; ++n0; }
+            }
+            int n1 = orc_retain_best(rs, id, n0, 2 * q);
+            for (int i = 0; i < n1; ++i) rs[i] = harris_response(lv, w, id[i] % w, id[i] / w);
+            int n2k = orc_retain_best(rs, id, n1, q);
+            for (int i = 0; i < n2k; ++i) {
+                if (nk >= cap) { ovf |= ORC_OVF_ORB_KEYPOINTS; break; }
+                const int x = id[i] % w, y = id[i] / w;
+                orc_keypoint *k = &kps[nk++];
+                k->lx = x; k->ly = y; k->octave = l; k->response = harris_response(lv, w, x, y);
+                k->angle = ic_angle(lv, w, x, y);
+                k->x = (float)x * L.scale[l];
+                k->y = (float)y * L.scale[l];
+            }
+            free(rs); free(id);
+            continue;
+        }
         /* retainBest(2*quota) on the FAST score: keep every keypoint whose score
          * >= the (2q)-th best score (keypoint.cpp) */
         int hist[256]; memset(hist, 0, sizeof(hist));

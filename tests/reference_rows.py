@@ -48,3 +48,26 @@ def rotation_errors(ds, R_rel, geometry):
         Rp = geometry.euler_to_rotation(g1[5], g1[4], g1[3], conv)
         err[i] = geometry.rotation_error(Rp @ np.asarray(R).reshape(3, 3), geometry.euler_to_rotation(g2[5], g2[4], g2[3], conv))
     return err
+
+
+def euler_agreement(ds, R_rel, geometry):
+    """Per pair: largest wrapped difference (degrees) between the forward Euler triple of R_prev_GT @ R_rel
+    (batch_processor.py:82-101) and the est_yaw / est_pitch / est_roll the reference's CSV holds for that row."""
+    conv = ds["convention"]
+    cols = ds["columns"]
+    ref = ds["table"][:, [cols.index("est_yaw"), cols.index("est_pitch"), cols.index("est_roll")]]
+    out = np.zeros(len(R_rel))
+    for i, R in enumerate(R_rel):
+        g1 = ds["gt1"][i]
+        Rp = geometry.euler_to_rotation(g1[5], g1[4], g1[3], conv)
+        e = np.array(geometry.rotation_to_euler(Rp @ np.asarray(R).reshape(3, 3), conv))
+        d = np.abs((e - ref[i] + 180.0) % 360.0 - 180.0)
+        out[i] = d.max()
+    return out
+
+
+AGREE_EDGES = (1e-6, 1e-3, 0.01, 0.1, 0.5)
+
+
+def agreement_counts(diff):
+    return [int((diff < e).sum()) for e in AGREE_EDGES]
