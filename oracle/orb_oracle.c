@@ -43,6 +43,8 @@ static int cv_round(double v) { return (int)lrint(v); }
  * 1 = electors only, the one-pass rule of older OpenCV that rounds 1-2 restated; match_oracle.c).  Defaults are what the HIP path implements. */
 static int g_variant[4] = {0, 0, 0, 0};
 int orc_retain_best(const float *resp, int32_t *ids, int n, int n_points);   /* retain_best.cpp */
+int orc_retain_best_llvm(const float *resp, int32_t *ids, int n, int n_points);
+int orc_retain_best_msvc(const float *resp, int32_t *ids, int n, int n_points);
 void orc_debug_set_variant(int key, int val) { if (key >= 0 && key < 4) g_variant[key] = val; }
 int orc_debug_get_variant(int key) { return key >= 0 && key < 4 ? g_variant[key] : 0; }
 
@@ -184,13 +186,15 @@ static void blur_level_float(const uint8_t *src, int w, int h, uint8_t *dst)
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
             float s = g[0] * (float)src[(size_t)y * w + refl(x - 3, w)];
-            for (int k = 1; k < 7; ++k) s += g[k] * (float)src[(size_t)y * w + refl(x + k - 3, w)];
+            if (g_variant[0] == 3) for (int k = 1; k < 7; ++k) s = fmaf(g[k], (float)src[(size_t)y * w + refl(x + k - 3, w)], s);
+            else for (int k = 1; k < 7; ++k) s += g[k] * (float)src[(size_t)y * w + refl(x + k - 3, w)];
             tmp[(size_t)y * w + x] = s;
         }
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
             float s = g[3] * tmp[(size_t)y * w + x];
-            for (int k = 1; k <= 3; ++k) s += g[3 + k] * (tmp[(size_t)refl(y + k, h) * w + x] + tmp[(size_t)refl(y - k, h) * w + x]);
+            if (g_variant[0] == 3) for (int k = 1; k <= 3; ++k) s = fmaf(g[3 + k], tmp[(size_t)refl(y + k, h) * w + x] + tmp[(size_t)refl(y - k, h) * w + x], s);
+            else for (int k = 1; k <= 3; ++k) s += g[3 + k] * (tmp[(size_t)refl(y + k, h) * w + x] + tmp[(size_t)refl(y - k, h) * w + x]);
             long r = lrintf(s);
             dst[(size_t)y * w + x] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
         }
@@ -199,7 +203,7 @@ static void blur_level_float(const uint8_t *src, int w, int h, uint8_t *dst)
 
 void orc_orb_blur_level(const uint8_t *src, int w, int h, uint8_t *dst)
 {
-    if (g_variant[0] == 2) { blur_level_float(src, w, h, dst); return; }
+    if (g_variant[0] >= 2) { blur_level_float(src, w, h, dst); return; }
     const int *GK = GK_TAB[g_variant[0] & 1];
     uint16_t *tmp = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)w * h);
     for (int y = 0; y < h; ++y)
@@ -363,7 +367,8 @@ int orc_orb_detect_and_compute_ex(const uint8_t *img, int W, int H, int nfeature
         uint8_t *sm = smap + L.offset[l], *nm = nmap + L.offset[l];
         orc_orb_fast_score_map(lv, w, h, fast_threshold, sm);
         orc_orb_nms_map(sm, w, h, nm);
-        if (g_variant[1] == 3) {
+        if (g_variant[1] >= 3) {
+            int (*retain)(const float *, int32_t *, int, int) = g_variant[1] == 5 ? orc_retain_best_msvc : g_variant[1] == 4 ? orc_retain_best_llvm : orc_retain_best;
             /* cv2's own keypoint order: FAST's raster emission -> retainBest(2q) on the FAST score -> Harris ->
              * retainBest(q), both through libstdc++'s std::nth_element + std::partition (retain_best.cpp) */
             int total0 = 0;
@@ -375,9 +380,9 @@ int orc_orb_detect_and_compute_ex(const uint8_t *img, int W, int H, int nfeature
                 int v = nm[(size_t)y * w + x];
                 if (v) { rs[n0] = (float)v; id[n0] = y * w + x; ++n0; }
             }
-            int n1 = orc_retain_best(rs, id, n0, 2 * q);
+            int n1 = retain(rs, id, n0, 2 * q);
             for (int i = 0; i < n1; ++i) rs[i] = harris_response(lv, w, id[i] % w, id[i] / w);
-            int n2k = orc_retain_best(rs, id, n1, q);
+            int n2k = retain(rs, id, n1, q);
             for (int i = 0; i < n2k; ++i) {
                 if (nk >= cap) { ovf |= ORC_OVF_ORB_KEYPOINTS; break; }
                 const int x = id[i] % w, y = id[i] / w;
