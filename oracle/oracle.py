@@ -239,6 +239,16 @@ def set_variant(key, val):
     lib().orc_debug_set_variant(int(key), int(val))
 
 
+STL = {"libstdc++": 3, "msvc": 5, "libc++": 4}
+
+
+def set_stl(name="libstdc++"):
+    """Which C++ runtime's std::nth_element orders the keypoints inside a level (cv2's retainBest): the Linux
+    wheels (default, the reference's Dockerfile), the Windows wheels ('msvc': the reference's simulator result file
+    was produced by one) or the macOS wheels ('libc++')."""
+    set_variant(1, STL[name])
+
+
 def estimate_pose_batch(imgs1, imgs2, K, nfeatures=4000, max_matches=500, nthreads=1, method="ORB", return_points=False):
     imgs1 = np.ascontiguousarray(imgs1, np.uint8); imgs2 = np.ascontiguousarray(imgs2, np.uint8)
     K = np.ascontiguousarray(K, np.float64)

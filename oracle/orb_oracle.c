@@ -34,14 +34,19 @@
 
 static int cv_round(double v) { return (int)lrint(v); }
 
-/* Experiment knobs (tools/reference_rows.py): conventions cv2 leaves implementation-defined or that this
- * restatement had to guess.  Key 0: Gaussian taps (0 = [18,34,49,55,...] = cvRound(256 g_i), sum 257, the
- * sepFilter2D fixed-point route ORB's in-place blur of a pyramid sub-matrix takes; 1 = [18,34,48,56,...],
- * the sum-256 set of round 1).  Key 1: keypoint order inside a level (0 = raster; 1 = Harris response
- * descending, raster on ties; 2 = reverse raster; 3 = cv2's own order: both retainBest calls through the real
- * std::nth_element + std::partition, retain_best.cpp).  Key 2: crossCheck rule of the matcher (0 = strict mutual, cv2 >= 4.5.x;
- * 1 = electors only, the one-pass rule of older OpenCV that rounds 1-2 restated; match_oracle.c).  Defaults are what the HIP path implements. */
-static int g_variant[4] = {0, 0, 0, 0};
+/* Convention knobs.  The DEFAULTS are what the reference's 147 committed answers pin (tools/forensic*.py,
+ * tools/agree.py, tests/test_reference_rows_cpu.py) and what the HIP path implements; the other values are the
+ * hypotheses that evidence ruled out, kept for the record and for the experiment tools.
+ * Key 0, descriptor blur: 3 = sepFilter2D's f32 route with fused multiply-adds (the AVX2-dispatched build of
+ *   filter.simd.hpp contracts s += f * x), DEFAULT; 2 = the same unfused; 1 = fixed-point taps [18,34,48,56,...] (sum 256);
+ *   0 = fixed-point taps cvRound(256 g) = [18,34,49,55,...] (sum 257, rounds 1-2).
+ * Key 1, keypoint order inside a level: 3 = cv2's own on libstdc++ (Linux wheels; the reference's Dockerfile), DEFAULT:
+ *   both retainBest calls through the real std::nth_element + std::partition; 5 = the same on the MSVC STL (Windows
+ *   wheels: the simulator result file was produced there); 4 = on libc++ (macOS wheels); 0 = raster, 1 = Harris response
+ *   descending, 2 = reverse raster (rounds 1-2).
+ * Key 2, crossCheck rule: 0 = strict mutual nearest neighbours (OpenCV >= 4.5.x), DEFAULT; 1 = electors only. */
+static int g_variant[4] = {3, 3, 0, 0};
+int orc_orb_corner_cap(int w, int h) { int c = (int)(((long long)w * h) / 64); return c < 1024 ? 1024 : c > 8192 ? 8192 : c; }
 int orc_retain_best(const float *resp, int32_t *ids, int n, int n_points);   /* retain_best.cpp */
 int orc_retain_best_llvm(const float *resp, int32_t *ids, int n, int n_points);
 int orc_retain_best_msvc(const float *resp, int32_t *ids, int n, int n_points);
@@ -368,19 +373,24 @@ int orc_orb_detect_and_compute_ex(const uint8_t *img, int W, int H, int nfeature
         orc_orb_fast_score_map(lv, w, h, fast_threshold, sm);
         orc_orb_nms_map(sm, w, h, nm);
         if (g_variant[1] >= 3) {
+            /* cv2's own keypoint order (orb.cpp computeKeyPoints): FAST's raster emission -> retainBest(2q) on the FAST
+             * score -> Harris -> retainBest(q), both through the C++ runtime's std::nth_element + std::partition
+             * (retain_best.cpp).  Workspace capacities of the HIP path, mirrored here so that a truncated image
+             * compares equal too (cv2 has none; both raise ORC_OVF_ORB_CANDIDATES): the raster corner list holds
+             * orc_orb_corner_cap(w, h) entries (first in raster order), the list after the first retainBest 4q + 256. */
             int (*retain)(const float *, int32_t *, int, int) = g_variant[1] == 5 ? orc_retain_best_msvc : g_variant[1] == 4 ? orc_retain_best_llvm : orc_retain_best;
-            /* cv2's own keypoint order: FAST's raster emission -> retainBest(2q) on the FAST score -> Harris ->
-             * retainBest(q), both through libstdc++'s std::nth_element + std::partition (retain_best.cpp) */
-            int total0 = 0;
-            for (int y = EDGE; y < h - EDGE; ++y) for (int x = EDGE; x < w - EDGE; ++x) if (nm[(size_t)y * w + x]) ++total0;
-            float *rs = (float *)malloc(sizeof(float) * (size_t)(total0 + 1));
-            int32_t *id = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total0 + 1));
+            const int ccap = orc_orb_corner_cap(w, h), kcap2 = 4 * q + 256;
+            float *rs = (float *)malloc(sizeof(float) * (size_t)(ccap + 1));
+            int32_t *id = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ccap + 1));
             int n0 = 0;
             for (int y = EDGE; y < h - EDGE; ++y) for (int x = EDGE; x < w - EDGE; ++x) {
                 int v = nm[(size_t)y * w + x];
-                if (v) { rs[n0] = (float)v; id[n0] = y * w + x; ++n0; }
+                if (!v) continue;
+                if (n0 >= ccap) { ovf |= ORC_OVF_ORB_CANDIDATES; continue; }
+                rs[n0] = (float)v; id[n0] = y * w + x; ++n0;
             }
             int n1 = retain(rs, id, n0, 2 * q);
+            if (n1 > kcap2) { n1 = kcap2; ovf |= ORC_OVF_ORB_CANDIDATES; }
             for (int i = 0; i < n1; ++i) rs[i] = harris_response(lv, w, id[i] % w, id[i] / w);
             int n2k = retain(rs, id, n1, q);
             for (int i = 0; i < n2k; ++i) {

@@ -93,15 +93,19 @@ def test_five_point_recovers_true_essential(oracle):
     assert np.median(errs) < 1e-10 and max(errs) < 1e-5
 
 
-def _np_crosscheck(d1, d2, max_matches):
-    """App. A.2 restated in numpy/python (small cases only)."""
+def _np_crosscheck(d1, d2, max_matches, electors_only=False):
+    """batchDistance(crosscheck=true) restated in numpy/python (small cases only): every train elects its nearest
+    query, every query keeps its best elector, and (OpenCV >= 4.5.x, the second pass) the match survives only if the
+    query's own nearest train elected it.  electors_only = the one-pass rule of older OpenCV (rounds 1-2)."""
     D = np.array([[bin(int.from_bytes(bytes(a ^ b), "little")).count("1") for b in d2] for a in d1]).reshape(len(d1), len(d2))
     best = {}
-    for j in range(len(d2)):
-        i = int(np.argmin(D[:, j]))             # lowest i on ties
+    tidx = [int(np.argmin(D[:, j])) for j in range(len(d2))]      # lowest i on ties
+    for j, i in enumerate(tidx):
         d = int(D[i, j])
         if i not in best or d < best[i][0]:
             best[i] = (d, j)
+    if not electors_only:
+        best = {i: v for i, v in best.items() if tidx[int(np.argmin(D[i, :]))] == i}      # sidx[i] = lowest j on ties
     m = sorted(((d, i, j) for i, (d, j) in sorted(best.items())), key=lambda x: x[0])   # stable: ascending i inside equal d
     return m[:max_matches]
 
@@ -117,6 +121,29 @@ def test_matcher_matches_numpy_restatement(oracle):
         assert [(int(a), int(b), int(c)) for a, b, c in zip(d, q, t)] == exp
     q, t, d = oracle.match_hamming(np.zeros((0, 32), np.uint8), d2, 10)
     assert len(q) == 0
+
+
+def test_matcher_mutual_rule_differs_from_electors_only(oracle):
+    """A case where the two crossCheck rules part: query 1's only elector is train 1, but query 1's own nearest train is
+    train 0, which elected query 0 -- OpenCV >= 4.5.x drops (1, 1), the older one-pass rule kept it."""
+    d1 = np.zeros((2, 32), np.uint8); d2 = np.zeros((2, 32), np.uint8)
+    d1[0, 0] = 0b0000; d1[1, 0] = 0b0111
+    d2[0, 0] = 0b0001; d2[1, 0] = 0b11111
+    # distances: d(q0,t0)=1 d(q0,t1)=5 d(q1,t0)=2 d(q1,t1)=2 -> t0 elects q0, t1 elects q1; q1's nearest train is t0 (tie -> lowest)
+    assert _np_crosscheck(d1, d2, 10, electors_only=True) == [(1, 0, 0), (2, 1, 1)]
+    assert _np_crosscheck(d1, d2, 10) == [(1, 0, 0)]
+    q, t, d = oracle.match_hamming(d1, d2, 10)
+    assert list(zip(d.tolist(), q.tolist(), t.tolist())) == [(1, 0, 0)]
+    a = d1.astype(np.float32); b = d2.astype(np.float32)
+    q, t, dd = oracle.match_l2(a, b, 10)
+    # L2 on the same bytes: |7-1| = 6, |7-31| = 24 -> q1's nearest train is t0, which elected q0 (|0-1| = 1): (1, 1) is dropped again
+    assert list(zip(q.tolist(), t.tolist())) == [(0, 0)]
+    try:
+        oracle.set_variant(2, 1)
+        q, t, d = oracle.match_hamming(d1, d2, 10)
+        assert list(zip(d.tolist(), q.tolist(), t.tolist())) == [(1, 0, 0), (2, 1, 1)]
+    finally:
+        oracle.set_variant(2, 0)
 
 
 def test_l2_matcher_ordering(oracle):
@@ -164,18 +191,29 @@ def test_orb_properties(oracle, K_vga):
         k = kps[kps["octave"] == l]
         assert np.all((k["lx"] >= 31) & (k["lx"] < L.w[l] - 31) & (k["ly"] >= 31) & (k["ly"] < L.h[l] - 31))
         order = k["ly"].astype(np.int64) * 4096 + k["lx"]
-        assert np.all(np.diff(order) > 0)                            # raster order inside a level
+        assert len(np.unique(order)) == len(order)                   # no keypoint twice
+        # inside a level the order is what cv2's retainBest (std::nth_element + std::partition) leaves behind: raster
+        # where nothing had to be dropped, scrambled otherwise -- but the SET is always "the quota best by response"
         assert len(k) >= min(L.quota[l], len(k))
     assert np.all((kps["angle"] >= 0) & (kps["angle"] <= 360))
     k2, d2 = oracle.orb_detect_and_compute(img, 1000)
     assert np.array_equal(desc, d2)
-    # blur: taps cvRound(256 g_i) = [18,34,49,55,49,34,18] sum to 257 (cv2's sepFilter2D fixed-point route does not
-    # renormalise): a constant c becomes (c * 257^2 + 2^15) >> 16, saturated; impulse response = outer(k, k) / 2^16
-    assert np.all(oracle.blur_level(np.full((40, 50), 93, np.uint8)) == (93 * 257 * 257 + 32768) >> 16)
+    # the same keypoint SET under every order convention (the order knob only permutes inside a level)
+    try:
+        oracle.set_variant(1, 0)
+        kr, _ = oracle.orb_detect_and_compute(img, 1000)
+    finally:
+        oracle.set_variant(1, 3)
+    key = lambda a: sorted(zip(a["octave"].tolist(), a["ly"].tolist(), a["lx"].tolist()))
+    assert key(kr) == key(kps)
+    # blur = sepFilter2D's f32 route (normalised Gaussian taps): constants are preserved, the impulse response is
+    # cvRound(255 g_i g_j), symmetric, and sums to ~255
+    assert np.all(oracle.blur_level(np.full((40, 50), 93, np.uint8)) == 93)
     assert np.all(oracle.blur_level(np.full((40, 50), 255, np.uint8)) == 255)
     imp = np.zeros((21, 21), np.uint8); imp[10, 10] = 255
-    k = np.array([18, 34, 49, 55, 49, 34, 18])
-    assert np.array_equal(oracle.blur_level(imp)[7:14, 7:14], (np.outer(k, k) * 255 + 32768) >> 16)
+    g = np.exp(-0.125 * np.arange(-3, 4) ** 2); g /= g.sum()
+    out = oracle.blur_level(imp)[7:14, 7:14]
+    assert np.array_equal(out, np.rint(np.outer(g, g) * 255).astype(np.uint8)) and np.array_equal(out, out.T)
     assert abs(oracle.fast_atan2(1.0, 1.0) - 45) < 0.02 and abs(oracle.fast_atan2(-1.0, 0.0) - 270) < 0.02
 
 

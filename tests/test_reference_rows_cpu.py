@@ -2,13 +2,20 @@
 committed evaluation runs (evaluation-runs/*/results/evaluation_results.csv: simulator 58, Salah 80,
 phone 9), on the committed image pairs, each with its run script's camera matrix.
 
-What can and cannot agree: cv2 is not available offline, so keypoint ORDER (std::nth_element-defined in
-cv2) differs from the oracle's raster order; matcher ties and the top-500 cut then pick other matches and the
-fixed-seed RANSAC sample stream lands on other points.  One pair's error therefore moves as under a change of
-the RANSAC seed, and agreement is statistical.  The test measures that spread (RANSAC + recoverPose replayed
-from the matched points under other seeds) and asserts that the reference's per-dataset median lies inside
-it, that the oracle's typical median is not worse than the reference's, and that its default-seed run is
-not an outlier of its own spread.  Numbers observed are in DESIGN.md section 2.
+PER-PAIR pin.  The forward Euler triple of R_prev_GT @ R_rel (batch_processor.py:82-101) is compared with the
+est_yaw / est_pitch / est_roll columns.  cv2's findEssentialMat returns the model of ONE minimal five-point sample
+without a refit, so a row agrees to ~1e-9 degrees only if keypoints, their ORDER, descriptors, the match list, its
+sort, the RANSAC sample stream and the winning model are all cv2's -- or it does not agree at all.  Rounds 1-2 had
+0 / 147 rows inside 0.01 degrees.  Three conventions, each identified from these very rows (tools/forensic*.py,
+tools/agree.py), brought that to 126 / 147 inside 1e-6 degrees:
+  * the descriptor blur is sepFilter2D's f32 route with fused multiply-adds, not a fixed-point kernel;
+  * BFMatcher(crossCheck=True) is strict mutual nearest neighbours (OpenCV >= 4.5.x);
+  * the keypoint order inside a level is what std::nth_element + std::partition leave behind in retainBest --
+    libstdc++'s for the Salah and phone files (Linux wheels), the MSVC STL's for the simulator file (a Windows
+    wheel produced it: 47 / 58 rows against 10 / 58 with libstdc++'s order).
+The rows that still differ are low-parallax pairs whose winner hangs on one or two borderline inliers (five of the
+simulator's are pairs of IDENTICAL frames): there the last bits of cv2's own SVD / solvePoly decide, and those are not
+restated (geom_oracle.c says how its solver differs).
 """
 import os
 
@@ -18,65 +25,57 @@ import pytest
 from relative_pose_estimation_amd import geometry
 from tests import reference_rows as rr
 
-NSEEDS = 24
 NTHREADS = max(1, min(16, os.cpu_count() or 1))
+# which C++ runtime's nth_element ordered the keypoints of each result file, and the agreement floor (rows inside
+# 1e-6 degrees; measured: 47 / 71 / 8)
+RUNTIME = {"sim": "msvc", "salah": "libstdc++", "phone": "libstdc++"}
+FLOOR = {"sim": 45, "salah": 69, "phone": 8}
 
 
 @pytest.fixture(scope="module")
 def oracle():
     from oracle import oracle as o
     yield o
+    o.set_stl("libstdc++")
     o.set_ransac_seed()
-
-
-def _run(oracle, name):
-    ds = rr.load(name)
-    oracle.set_ransac_seed()
-    out, pts = oracle.estimate_pose_batch(ds["img1"], ds["img2"], ds["K"], 4000, 500, nthreads=NTHREADS,
-                                          return_points=True)                  # pipeline.py:94-101 parameters
-    err = rr.rotation_errors(ds, out["R"], geometry)
-    sweep = []
-    for s in range(NSEEDS):
-        oracle.set_ransac_seed((0x9E3779B97F4A7C15 * (s + 1)) & 0xFFFFFFFFFFFFFFFF)
-        o2 = oracle.pose_from_points_batch(pts, out["n_matches"], ds["K"], NTHREADS)
-        assert np.all(o2["status"] == 0)
-        sweep.append(rr.rotation_errors(ds, o2["R"], geometry))
-    oracle.set_ransac_seed()
-    # replaying the default seed from the points reproduces the end-to-end run bit for bit
-    o3 = oracle.pose_from_points_batch(pts, out["n_matches"], ds["K"], NTHREADS)
-    assert np.array_equal(o3["R"], out["R"]) and np.array_equal(o3["inliers"], out["inliers"])
-    return ds, out, err, np.array(sweep)
-
-
-def _report(name, ds, err, sweep):
-    ref = ds["ref_rotation_error"]
-    meds = np.median(sweep, axis=1)
-    lo, hi = sweep.min(0), sweep.max(0)
-    edges = [0, 0.25, 0.5, 1, 2, 5, 10, 45, 90, 181]
-    print(f"\n[{name}] {len(ref)} pairs: oracle median {np.median(err):.3f} deg (default seed), reference {np.median(ref):.3f};"
-          f" seed sweep x{len(sweep)}: medians min {meds.min():.3f} / median {np.median(meds):.3f} / max {meds.max():.3f}")
-    print(f"[{name}] reference error inside the oracle's per-pair seed range: {int(((ref >= lo) & (ref <= hi)).sum())}/{len(ref)};"
-          f" flips (> 90 deg): oracle {int((err > 90).sum())} (sweep mean {np.mean((sweep > 90).sum(1)):.1f}), reference {int((ref > 90).sum())}")
-    print(f"[{name}] histogram of rotation error, edges {edges}:\n   oracle    {np.histogram(err, edges)[0].tolist()}"
-          f"\n   reference {np.histogram(ref, edges)[0].tolist()}")
-    d = err - ref
-    print(f"[{name}] per-pair oracle - reference: within 0.5 deg {int((np.abs(d) <= 0.5).sum())}, oracle worse {int((d > 0.5).sum())}, better {int((d < -0.5).sum())}")
-    return meds
 
 
 @pytest.mark.parametrize("name", rr.NAMES)
 def test_all_reference_rows(oracle, name):
-    ds, out, err, sweep = _run(oracle, name)
+    ds = rr.load(name)
+    oracle.set_ransac_seed()
+    oracle.set_stl(RUNTIME[name])
+    out = oracle.estimate_pose_batch(ds["img1"], ds["img2"], ds["K"], 4000, 500, nthreads=NTHREADS)   # pipeline.py:94-101 parameters
+    oracle.set_stl("libstdc++")
     ref = ds["ref_rotation_error"]
     assert np.all(out["status"] == 0)                       # the reference estimated every one of these pairs
     assert np.all((out["n_matches"] >= 5) & (out["n_matches"] <= 500))   # max_matches = 500 (pose_estimator.py:150-151)
-    meds = _report(name, ds, err, sweep)
-    ref_med = np.median(ref)
-    # 1. the reference's median lies inside the oracle's seed spread
-    assert meds.min() <= ref_med <= meds.max(), (meds.min(), ref_med, meds.max())
-    # 2. the oracle's typical median is not worse than the reference's (10 % slack = well inside the spread)
-    assert np.median(meds) <= 1.10 * ref_med, (np.median(meds), ref_med)
-    # 3. the default-seed run is one of that family
-    assert np.median(err) <= meds.max() * 1.15
-    # 4. gross failures (pose flips) are the reference's own: no more of them on average
-    assert np.mean((sweep > 90).sum(1)) <= (ref > 90).sum() + 1.0
+    diff = rr.euler_agreement(ds, out["R"], geometry)
+    err = rr.rotation_errors(ds, out["R"], geometry)
+    counts = rr.agreement_counts(diff)
+    print(f"\n[{name}] {len(ref)} rows, keypoint order of {RUNTIME[name]}: est_* agree within "
+          + ", ".join(f"{e:g} deg: {c}" for e, c in zip(rr.AGREE_EDGES, counts)))
+    print(f"[{name}] median rotation error: oracle {np.median(err):.3f} deg, reference {np.median(ref):.3f};"
+          f" flips (> 90 deg): oracle {int((err > 90).sum())}, reference {int((ref > 90).sum())}")
+    print(f"[{name}] rows outside 1e-6 deg (frame: difference): "
+          + ", ".join(f"{int(f)}: {d:.2g}" for f, d in zip(ds["frames2"], diff) if d >= 1e-6))
+    assert counts[0] >= FLOOR[name], counts
+    # rotation error <= reference on identical inputs (BASELINE.json north_star): on the agreeing rows it IS the reference's
+    # error; over the whole file the median may not be worse by more than the few non-agreeing rows can move it
+    agree = diff < 1e-6
+    assert np.allclose(err[agree], ref[agree], atol=1e-5)
+    assert np.median(err) <= 1.05 * np.median(ref) + 1e-9, (np.median(err), np.median(ref))
+
+
+def test_wrong_conventions_do_not_agree(oracle):
+    """The pin is sharp: each of the three conventions alone, set to its round-2 value, loses the phone rows."""
+    ds = rr.load("phone")
+    try:
+        for key, val in ((0, 0), (1, 0), (2, 1)):
+            oracle.set_variant(key, val)
+            out = oracle.estimate_pose_batch(ds["img1"], ds["img2"], ds["K"], 4000, 500, nthreads=NTHREADS)
+            n = rr.agreement_counts(rr.euler_agreement(ds, out["R"], geometry))[0]
+            oracle.set_variant(key, {0: 3, 1: 3, 2: 0}[key])
+            assert n <= 3, (key, val, n)
+    finally:
+        oracle.set_variant(0, 3); oracle.set_variant(1, 3); oracle.set_variant(2, 0)
