@@ -255,8 +255,10 @@ def run_workload(args, method, sub, data, rank, world, device, comm_kind):
         assert S == 1 and sub >= B, "multi-GPU runs use one handle and one launch group per rank"
         if comm_kind == "rccl":
             try:
-                comm = sharding.PoseComm(eng, rank, world, tag=f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{args.config}{int(args.stream)}")
-            except Exception as exc:       # librccl missing / bootstrap refused on this node: say so and still deliver the records
+                comm = sharding.PoseComm(eng, rank, world, tag=f"{args.config}{int(args.stream)}")
+            except sharding.CommUnavailable as exc:
+                # raised by EVERY rank (the ranks agree on the outcome of each set-up phase, sharding.PoseComm): all of them
+                # say so and deliver the 128-byte records through torch.distributed instead
                 sys.stderr.write(f"[bench] rank {rank}: native RCCL pose gather unavailable ({exc}); using torch.distributed gloo for the 128-B records\n")
                 comm_kind = "gloo (RCCL gather unavailable)"
         if comm is None:
@@ -452,13 +454,35 @@ def run_workload(args, method, sub, data, rank, world, device, comm_kind):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver would
+    (python -m torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1), as a CHILD process -- nothing in this
+    process has touched the GPU yet, and nothing will -- and hand its exit code on.  A 1-GPU line for an N-GPU request
+    is never printed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stderr.write(f"[bench] --gpus {args.gpus} without WORLD_SIZE in the environment: launching {' '.join(cmd[1:8])} ...\n")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without a launcher)")
     method, sub = resolve(args)
     cores = os.cpu_count() or 1
     workers = args.gen_workers or max(1, min(16, cores // max(1, world)))

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RPE_ABI_VERSION 2
+#define RPE_ABI_VERSION 3
 #define RPE_ORB_LEVELS 12
 
 /* per-pair status codes (status[] outputs) */
@@ -55,7 +55,7 @@ enum {
 /* Capacity flags of the last batch (rpe_fetch_overflow): a fixed-size workspace truncated a list that cv2
  * would have kept whole, so the pair's features differ from the reference's although status is RPE_PAIR_OK. */
 enum {
-    RPE_OVF_ORB_CANDIDATES = 1 << 0,   /* a pyramid level had more than 4*quota+256 FAST candidates at the retainBest(2*quota) score */
+    RPE_OVF_ORB_CANDIDATES = 1 << 0,   /* a pyramid level had more FAST corners than clamp(w h / 64, 1024, 8192), or more than 4*quota+256 survived retainBest(2*quota) (score ties) */
     RPE_OVF_ORB_KEYPOINTS  = 1 << 1,   /* more than nfeatures+64 keypoints after the Harris retainBest (ties) */
     RPE_OVF_SIFT_SEEDS     = 1 << 4,   /* more scale-space extrema than base_pixels/16 */
     RPE_OVF_SIFT_RAW       = 1 << 5,   /* more oriented keypoints than the raw list holds */
@@ -78,6 +78,14 @@ enum { RPE_NORM_HAMMING = 0, RPE_NORM_L2 = 1 };
  * RPE_MATCH_RATIO = opt-in extension named by the project brief, NOT in the reference: knnMatch(k=2) + Lowe's
  * ratio test (best < ratio * second best), no cross check; then the same sort / top-max_matches. */
 enum { RPE_MATCH_CROSSCHECK = 0, RPE_MATCH_RATIO = 1 };
+/* Which C++ runtime's std::nth_element / std::partition orders the ORB keypoints inside a pyramid level.  cv2's
+ * KeyPointsFilter::retainBest (called twice per level by ORB, orb.cpp computeKeyPoints) leaves its vector in the
+ * order those two library calls happen to produce, descriptor rows follow that order, and BFMatcher ties / the
+ * reference's stable sort before the top-500 cut (pose_estimator.py:147-151) / the fixed-seed RANSAC then depend on
+ * it.  The reference's committed result files pin it row by row: RPE_STL_LIBSTDCXX reproduces the Salah and phone
+ * files (Linux wheels; the reference's Dockerfile is python:3.9-slim), RPE_STL_MSVC the simulator file (a Windows
+ * wheel produced it).  The keypoint SET is the same under both. */
+enum { RPE_STL_LIBSTDCXX = 0, RPE_STL_MSVC = 1 };
 
 /* Mirrors PoseEstimator.__init__ kwargs (pose_estimator.py:19-32) plus the
  * constants hard-coded at the reference's cv2 call sites. */
@@ -95,7 +103,7 @@ typedef struct rpe_config {
     double  ransac_prob;      /* 0.999                  (pose_estimator.py:525) */
     double  ransac_threshold; /* 1.0 px                 (pose_estimator.py:526) */
     int32_t match_mode;       /* RPE_MATCH_CROSSCHECK   (pose_estimator.py:131) */
-    int32_t reserved0;
+    int32_t stl_runtime;      /* RPE_STL_LIBSTDCXX: cv2's keypoint order on the reference's Linux wheels (see above) */
     double  match_ratio;      /* Lowe ratio for RPE_MATCH_RATIO (default 0.75; unused by the reference mode) */
 } rpe_config;
 
@@ -267,6 +275,11 @@ const char *rpe_stage_name(int stage);
 typedef struct rpe_comm rpe_comm;
 int rpe_comm_unique_id(uint8_t id[RPE_COMM_ID_BYTES]);
 int rpe_comm_create(rpe_handle *h, int rank, int world, const uint8_t id[RPE_COMM_ID_BYTES], rpe_comm **out);
+/* the same in two steps, for launchers that let the ranks agree in between (sharding.PoseComm): rpe_comm_prepare does
+ * everything that can fail on one rank alone (dlopen of librccl, device buffers), rpe_comm_connect enters the collective
+ * ncclCommInitRank -- a rank whose local step failed never leaves the others waiting inside it */
+int rpe_comm_prepare(rpe_handle *h, int rank, int world, rpe_comm **out);
+int rpe_comm_connect(rpe_comm *c, const uint8_t id[RPE_COMM_ID_BYTES]);
 int rpe_comm_destroy(rpe_comm *c);
 const char *rpe_comm_last_error(void);
 /* packs the results of the handle's last batch (n_local pairs, global indices first_pair ..) into records on the

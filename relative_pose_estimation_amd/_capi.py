@@ -11,12 +11,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RPE_LIB", os.path.join(_HERE, "librpe_amd.so"))   # RPE_LIB: diagnostic builds only
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 ORB_LEVELS = 12
 PAIR_OK, PAIR_NO_DESCRIPTORS, PAIR_INSUFFICIENT_MATCHES, PAIR_NO_ESSENTIAL, PAIR_AMBIGUOUS_ESSENTIAL = 0, 1, 2, 3, 4
 FEATURE_ORB, FEATURE_SIFT = 0, 1
 NORM_HAMMING, NORM_L2 = 0, 1
 MATCH_CROSSCHECK, MATCH_RATIO = 0, 1
+STL_LIBSTDCXX, STL_MSVC = 0, 1          # whose nth_element orders the keypoints (include/rpe_amd.h RPE_STL_*)
 # capacity flags (rpe_fetch_overflow)
 OVF_ORB_CANDIDATES, OVF_ORB_KEYPOINTS = 1 << 0, 1 << 1
 OVF_SIFT_SEEDS, OVF_SIFT_RAW, OVF_SIFT_PREFILTER, OVF_SIFT_CAP, OVF_SIFT_KEYPOINTS = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
@@ -35,7 +36,7 @@ EXPORTS = [
     "rpe_estimate_stream", "rpe_enqueue_stream_device",
     "rpe_bgr_to_gray_device", "rpe_bgr_to_gray", "rpe_lsd_detect",
     "rpe_fetch_overflow", "rpe_calibrate_valu", "rpe_calibrate_valu_name", "rpe_calibrate_hbm",
-    "rpe_comm_unique_id", "rpe_comm_create", "rpe_comm_destroy", "rpe_comm_last_error", "rpe_gather_poses",
+    "rpe_comm_unique_id", "rpe_comm_create", "rpe_comm_prepare", "rpe_comm_connect", "rpe_comm_destroy", "rpe_comm_last_error", "rpe_gather_poses",
     "rpe_comm_allreduce_max", "rpe_comm_barrier",
 ]
 
@@ -45,7 +46,7 @@ class Config(C.Structure):
                 ("max_batch", C.c_int32), ("feature_method", C.c_int32), ("norm_type", C.c_int32),
                 ("max_matches", C.c_int32), ("nfeatures", C.c_int32), ("fast_threshold", C.c_int32),
                 ("ransac_max_iters", C.c_int32), ("ransac_prob", C.c_double), ("ransac_threshold", C.c_double),
-                ("match_mode", C.c_int32), ("reserved0", C.c_int32), ("match_ratio", C.c_double)]
+                ("match_mode", C.c_int32), ("stl_runtime", C.c_int32), ("match_ratio", C.c_double)]
 
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("angle", "<f4"), ("response", "<f4"),
@@ -118,6 +119,8 @@ def load():
     lib.rpe_calibrate_hbm.argtypes = [vp, C.POINTER(C.c_double)]; lib.rpe_calibrate_hbm.restype = C.c_int
     lib.rpe_comm_unique_id.argtypes = [vp]; lib.rpe_comm_unique_id.restype = C.c_int
     lib.rpe_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]; lib.rpe_comm_create.restype = C.c_int
+    lib.rpe_comm_prepare.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]; lib.rpe_comm_prepare.restype = C.c_int
+    lib.rpe_comm_connect.argtypes = [vp, vp]; lib.rpe_comm_connect.restype = C.c_int
     lib.rpe_comm_destroy.argtypes = [vp]; lib.rpe_comm_destroy.restype = C.c_int
     lib.rpe_comm_last_error.argtypes = []; lib.rpe_comm_last_error.restype = C.c_char_p
     lib.rpe_gather_poses.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]; lib.rpe_gather_poses.restype = C.c_int
@@ -150,7 +153,7 @@ class Engine:
     def __init__(self, width, height, max_batch=1, nfeatures=4000, max_matches=500, device=0,
                  feature_method=FEATURE_ORB, norm_type=NORM_HAMMING, fast_threshold=15,
                  ransac_max_iters=1000, ransac_prob=0.999, ransac_threshold=1.0,
-                 match_mode=MATCH_CROSSCHECK, match_ratio=0.75):
+                 match_mode=MATCH_CROSSCHECK, match_ratio=0.75, stl_runtime=STL_LIBSTDCXX):
         self.lib = load()
         cfg = Config()
         self.lib.rpe_default_config(C.byref(cfg))
@@ -158,7 +161,7 @@ class Engine:
         cfg.feature_method = feature_method; cfg.norm_type = norm_type
         cfg.max_matches = max_matches; cfg.nfeatures = nfeatures; cfg.fast_threshold = fast_threshold
         cfg.ransac_max_iters = ransac_max_iters; cfg.ransac_prob = ransac_prob; cfg.ransac_threshold = ransac_threshold
-        cfg.match_mode = match_mode; cfg.match_ratio = match_ratio
+        cfg.match_mode = match_mode; cfg.match_ratio = match_ratio; cfg.stl_runtime = stl_runtime
         self.cfg = cfg
         h = C.c_void_p()
         rc = self.lib.rpe_create(C.byref(cfg), C.byref(h))

@@ -89,28 +89,48 @@ extern "C" int rpe_comm_unique_id(uint8_t id[RPE_COMM_ID_BYTES])
     return RPE_OK;
 }
 
-extern "C" int rpe_comm_create(rpe_handle *h, int rank, int world, const uint8_t id[RPE_COMM_ID_BYTES], rpe_comm **out)
+// Set-up in two steps so that the ranks of a job can AGREE between them (sharding.PoseComm): everything that can fail
+// on one rank alone (loading librccl, device memory) happens in rpe_comm_prepare; only rpe_comm_connect enters the
+// collective ncclCommInitRank -- a rank that failed locally never leaves the others waiting inside it.
+extern "C" int rpe_comm_prepare(rpe_handle *h, int rank, int world, rpe_comm **out)
 {
-    if (!h || !id || !out || world < 1 || rank < 0 || rank >= world) return RPE_ERR_INVALID;
+    if (!h || !out || world < 1 || rank < 0 || rank >= world) return RPE_ERR_INVALID;
     *out = nullptr;
     int rc = load_rccl();
     if (rc) return rc;
     CHIP(hipSetDevice(h->cfg.device));
     rpe_comm *c = new rpe_comm();
     c->h = h; c->rank = rank; c->world = world;
-    ncclUniqueId u;
-    memcpy(u.internal, id, RPE_COMM_ID_BYTES);
-    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, u, rank);
-    if (r != 0) { g_comm_err = std::string("ncclCommInitRank failed: ") + g_rccl.GetErrorString(r); delete c; return RPE_ERR_HIP; }
     c->per_rank_cap = h->cfg.max_batch;
     const size_t rec = RPE_POSE_RECORD_BYTES;
     if (hipMalloc((void **)&c->d_send, rec * c->per_rank_cap) != hipSuccess ||
         hipMalloc((void **)&c->d_recv, rec * c->per_rank_cap * (size_t)world) != hipSuccess ||
         hipMalloc((void **)&c->d_scalar, sizeof(double) * 2) != hipSuccess) {
-        g_comm_err = "rpe_comm_create: hipMalloc failed"; rpe_comm_destroy(c); return RPE_ERR_HIP;
+        g_comm_err = "rpe_comm_prepare: hipMalloc failed"; rpe_comm_destroy(c); return RPE_ERR_HIP;
     }
     *out = c;
     return RPE_OK;
+}
+
+extern "C" int rpe_comm_connect(rpe_comm *c, const uint8_t id[RPE_COMM_ID_BYTES])
+{
+    if (!c || !id || c->comm) return RPE_ERR_INVALID;
+    CHIP(hipSetDevice(c->h->cfg.device));
+    ncclUniqueId u;
+    memcpy(u.internal, id, RPE_COMM_ID_BYTES);
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, c->world, u, c->rank);
+    if (r != 0) { c->comm = nullptr; g_comm_err = std::string("ncclCommInitRank failed: ") + g_rccl.GetErrorString(r); return RPE_ERR_HIP; }
+    return RPE_OK;
+}
+
+extern "C" int rpe_comm_create(rpe_handle *h, int rank, int world, const uint8_t id[RPE_COMM_ID_BYTES], rpe_comm **out)
+{
+    if (!id || !out) return RPE_ERR_INVALID;
+    int rc = rpe_comm_prepare(h, rank, world, out);
+    if (rc) return rc;
+    rc = rpe_comm_connect(*out, id);
+    if (rc) { rpe_comm_destroy(*out); *out = nullptr; }
+    return rc;
 }
 
 extern "C" int rpe_comm_destroy(rpe_comm *c)
@@ -152,7 +172,7 @@ __global__ __launch_bounds__(256) void pack_records_kernel(const double *__restr
 
 extern "C" int rpe_gather_poses(rpe_handle *h, rpe_comm *c, int n_local, int per_rank, int first_pair, void *h_records)
 {
-    if (!h || !c || c->h != h || !h_records || n_local < 0 || per_rank < 1 || n_local > per_rank) return RPE_ERR_INVALID;
+    if (!h || !c || !c->comm || c->h != h || !h_records || n_local < 0 || per_rank < 1 || n_local > per_rank) return RPE_ERR_INVALID;
     if (per_rank > c->per_rank_cap || n_local > h->cfg.max_batch) { g_comm_err = "rpe_gather_poses: per_rank exceeds the handle's max_batch"; return RPE_ERR_CAPACITY; }
     CHIP(hipSetDevice(h->cfg.device));
     hipLaunchKernelGGL(pack_records_kernel, dim3((per_rank + 255) / 256), dim3(256), 0, h->stream,
@@ -169,7 +189,7 @@ extern "C" int rpe_gather_poses(rpe_handle *h, rpe_comm *c, int n_local, int per
 // max over ranks of one host double (bench timing) -- doubles as the barrier of the step loop
 extern "C" int rpe_comm_allreduce_max(rpe_comm *c, double *value)
 {
-    if (!c || !value) return RPE_ERR_INVALID;
+    if (!c || !c->comm || !value) return RPE_ERR_INVALID;
     rpe_handle *h = c->h;
     CHIP(hipSetDevice(h->cfg.device));
     CHIP(hipMemcpyAsync(c->d_scalar, value, sizeof(double), hipMemcpyHostToDevice, h->stream));

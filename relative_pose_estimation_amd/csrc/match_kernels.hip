@@ -8,9 +8,12 @@
 // (8 dwords in VGPRs); query descriptors are staged through LDS in 1024-row tiles
 // with coalesced 16-B loads and read back as wave-uniform (broadcast) ds_read_b128;
 // distance = 8 x (v_xor_b32 + v_bcnt_u32_b32).  Selection follows
-// core/batch_distance.cpp (crosscheck=true): every train elects its nearest query
-// (strict '<', ascending query => lowest index on ties); every query keeps its best
-// elector through a packed (dist<<18 | trainIdx) LDS atomicMin (lowest train on ties).
+// core/batch_distance.cpp (crosscheck=true) of OpenCV >= 4.5.x, two passes: every train elects its nearest query
+// (strict '<', ascending query => lowest index on ties) and every query keeps its best elector through a packed
+// (dist<<18 | trainIdx) LDS atomicMin (lowest train on ties); then every query finds its OWN nearest train (same
+// key, lowest train on ties) and the match survives only if that train elected the query -- the two keys are
+// equal exactly then.  (Rounds 1-2 ran the first pass only, the rule of older OpenCV: a superset.  The reference's
+// result rows single out the two-pass rule: tests/test_reference_rows_cpu.py.)
 // The stable sort by distance is a bitonic sort of (dist<<16 | queryIdx) keys in LDS.
 //
 // RATIO = true is the opt-in extension named by the project brief and absent from the reference (which uses
@@ -21,6 +24,7 @@
 // point gather are shared.
 #include "rpe_internal.h"
 #include <stdlib.h>
+#include <algorithm>
 
 #define QTILE 1024
 
@@ -42,18 +46,22 @@ __global__ __launch_bounds__(256) void match_hamming_kernel(const uint8_t *__res
     extern __shared__ uint4 s_dyn[];
     uint4 *s_q = s_dyn;                                   // QTILE*2 uint4 = 32 KB (later: sort keys)
     unsigned *s_best = (unsigned *)(s_dyn + QTILE * 2);   // kcap entries
+    unsigned *s_row = s_best + kcap;                      // kcap entries: the query's own nearest train (second crossCheck pass)
     __shared__ int s_valid;
     const int tid = threadIdx.x, pair = blockIdx.x;
     const int img1 = pair, img2 = img2_base + pair;
     const int n1 = min(kp_count[img1], kcap), n2 = min(kp_count[img2], kcap);
-    for (int i = tid; i < n1; i += 256) s_best[i] = 0xFFFFFFFFu;
+    for (int i = tid; i < n1; i += 256) { s_best[i] = 0xFFFFFFFFu; s_row[i] = 0xFFFFFFFEu; }
     if (tid == 0) s_valid = 0;
     const uint4 *d1 = (const uint4 *)(desc + (long long)img1 * kcap * 32);
     const uint4 *d2 = (const uint4 *)(desc + (long long)img2 * kcap * 32);
     // owner descriptors (one per lane, in registers) x scanned descriptors (through LDS):
-    // crossCheck: owner = train j, scanned = queries; ratio: owner = query i, scanned = trains
-    const uint4 *d_own = RATIO ? d1 : d2, *d_scan = RATIO ? d2 : d1;
-    const int n_own = RATIO ? n1 : n2, n_scan = RATIO ? n2 : n1;
+    // crossCheck pass 0: owner = train j, scanned = queries; pass 1 and ratio: owner = query i, scanned = trains
+#pragma unroll 1
+    for (int pass = 0; pass < (RATIO ? 1 : 2); ++pass) {
+    const bool qown = RATIO || pass == 1;
+    const uint4 *d_own = qown ? d1 : d2, *d_scan = qown ? d2 : d1;
+    const int n_own = qown ? n1 : n2, n_scan = qown ? n2 : n1;
     for (int tc = 0; tc < n_own; tc += 256) {
         const int j = tc + tid;
         const bool valid = j < n_own;
@@ -90,10 +98,14 @@ __global__ __launch_bounds__(256) void match_hamming_kernel(const uint8_t *__res
             }
         }
         if (!RATIO) {
-            if (valid && n_scan > 0) atomicMin(&s_best[besti], ((unsigned)bestd << 18) | (unsigned)j);
+            if (valid && n_scan > 0) {
+                if (pass == 0) atomicMin(&s_best[besti], ((unsigned)bestd << 18) | (unsigned)j);
+                else s_row[j] = ((unsigned)bestd << 18) | (unsigned)besti;   // owner j is the query, besti its nearest train
+            }
         } else if (valid && n_scan >= 2 && (double)bestd < ratio * (double)second) {
             s_best[j] = ((unsigned)bestd << 18) | (unsigned)besti;          // owner j is the query, besti the train
         }
+    }
     }
     __syncthreads();
     // (dist, queryIdx) keys; unmatched queries sort to the end
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(256) void match_hamming_kernel(const uint8_t *__res
         unsigned key = 0xFFFFFFFFu;
         if (i < n1) {
             unsigned b = s_best[i];
-            if (b != 0xFFFFFFFFu) { key = ((b >> 18) << 16) | (unsigned)i; ++myvalid; }
+            if (b != 0xFFFFFFFFu && (RATIO || b == s_row[i])) { key = ((b >> 18) << 16) | (unsigned)i; ++myvalid; }
         }
         s_key[i] = key;
     }
@@ -144,7 +156,8 @@ __global__ __launch_bounds__(256) void match_hamming_kernel(const uint8_t *__res
 // O(N^2) part goes to v_mfma_i32_32x32x32_i8 (exact integers): 8 MFMAs = one 32 x 32 tile of q.t over K = 256.
 // What is left for the vector ALU per tile is the O(N) bit -> byte expansion and a 2-instruction epilogue per
 // accumulator: key = ((|q| + 512) << 16 | queryIdx) - (q.t << 17) (one v_mad_i32_i24), running v_min_u32 per train
-// column -- the minimum of (distance, queryIdx) keys IS batchDistance's "strict <, ascending query" election.
+// column -- the minimum of (distance, queryIdx) keys IS batchDistance's "strict <, ascending query" election.  The second
+// crossCheck pass (the query's own nearest train) is the same loop with the two descriptor sets swapped.
 // Workgroup = one pair, 8 waves; wave w owns train tile 8 p + w of pass p (its 32 descriptors expanded once into
 // 32 VGPRs: the B operand of all 8 K-steps), the query tiles stream through LDS, expanded by all 512 threads
 // (16 bits -> 16 bytes: nibble * 0x00204081 & 0x01010101), double buffered: one barrier per query tile.
@@ -165,41 +178,48 @@ __device__ __forceinline__ v4i_t expand16(unsigned b)
 
 __global__ __launch_bounds__(MM_NT) void match_hamming_mfma_kernel(const uint8_t *__restrict__ desc, const int *__restrict__ kp_count,
                                                                     const float2 *__restrict__ kp_pt, int img2_base, int kcap,
-                                                                    int max_matches,
+                                                                    int max_matches, int region0,
                                                                     int *__restrict__ m_q, int *__restrict__ m_t, int *__restrict__ m_d,
                                                                     int *__restrict__ m_n, float2 *__restrict__ pts1, float2 *__restrict__ pts2)
 {
     extern __shared__ uint4 s_dyn[];
-    // [0, 32 KB): two expanded query tiles (2 x 8 K-steps x 64 lanes x 16 B = 16 KB) + their packed (|q| + 512, index)
-    // words; reused as the sort-key array afterwards.  Then kcap election words.
+    // [0, region0 x 16 B): two expanded scanned tiles (2 x 8 K-steps x 64 lanes x 16 B = 16 KB) + their packed (|x| + 512, index)
+    // words + the popcounts; reused as the sort-key array afterwards.  Then kcap election words and kcap own-nearest words.
     v4i_t *s_a = (v4i_t *)s_dyn;                               // [2][8][64]
     unsigned *s_qpk = (unsigned *)(s_dyn + 2 * 8 * 64);        // [2][32]
-    unsigned *s_best = (unsigned *)(s_dyn + QTILE * 2);        // kcap entries (same offset as the VALU kernel: 32 KB)
+    unsigned *s_best = (unsigned *)(s_dyn + region0);          // kcap entries
+    unsigned *s_row = s_best + kcap;                           // kcap entries: the query's own nearest train (second crossCheck pass)
     __shared__ int s_valid;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pair = blockIdx.x;
     const int img1 = pair, img2 = img2_base + pair;
     const int n1 = min(kp_count[img1], kcap), n2 = min(kp_count[img2], kcap);
-    for (int i = tid; i < n1; i += MM_NT) s_best[i] = 0xFFFFFFFFu;
+    for (int i = tid; i < n1; i += MM_NT) { s_best[i] = 0xFFFFFFFFu; s_row[i] = 0xFFFFFFFEu; }
     if (tid == 0) s_valid = 0;
-    const unsigned *q32 = (const unsigned *)(desc + (long long)img1 * kcap * 32);      // 8 dwords per query descriptor
-    // |q| + 512 of every query, once (the four passes over the query tiles all need them); kept in the free part of the
-    // first 32 KB (kcap <= 8064 entries)
+    // |x| + 512 of every scanned descriptor, once per pass (the passes over the scanned tiles all need them); kept in the free
+    // part of the first 32 KB (kcap <= 8064 entries)
     unsigned short *s_qpop = (unsigned short *)(s_dyn + 2 * 8 * 64 + 16);
-    for (int i = tid; i < n1; i += MM_NT) {
+    const int h = lane >> 5, col = lane & 31;
+    // this thread's share of a scanned tile's expansion: item = tid: K-step s = tid >> 6, lane slot l = tid & 63
+    // (row = l & 31, half = l >> 5): the 16 bits [32 s + 16 half, +16) of scanned descriptor (tile * 32 + row)
+    const int xs = tid >> 6, xl = tid & 63, xrow = xl & 31, xh = xl >> 5;
+    // pass 0: the TRAINS own the MFMA columns and elect their nearest query (scanned through LDS);
+    // pass 1: the QUERIES own the columns and find their own nearest train -- the same loop with the roles swapped
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+    const int n_own = pass ? n1 : n2, n_scan = pass ? n2 : n1;
+    const unsigned *q32 = (const unsigned *)(desc + (long long)(pass ? img2 : img1) * kcap * 32);      // scanned: 8 dwords per descriptor
+    const uint4 *d2 = (const uint4 *)(desc + (long long)(pass ? img1 : img2) * kcap * 32);             // owners
+    __syncthreads();                                           // the previous pass is done with s_qpop
+    for (int i = tid; i < n_scan; i += MM_NT) {
         const uint4 a = ((const uint4 *)q32)[2 * i], b = ((const uint4 *)q32)[2 * i + 1];
         s_qpop[i] = (unsigned short)(512u + __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w));
     }
-    const uint4 *d2 = (const uint4 *)(desc + (long long)img2 * kcap * 32);
-    const int ntq = (n1 + 31) >> 5, ntt = (n2 + 31) >> 5;
-    const int h = lane >> 5, col = lane & 31;
-    // this thread's share of a query tile's expansion: item = tid: K-step s = tid >> 6, lane slot l = tid & 63
-    // (row = l & 31, half = l >> 5): the 16 bits [32 s + 16 half, +16) of query (tile * 32 + row)
-    const int xs = tid >> 6, xl = tid & 63, xrow = xl & 31, xh = xl >> 5;
-    for (int tt0 = 0; tt0 < ntt && n1 > 0; tt0 += 8) {
+    const int ntq = (n_scan + 31) >> 5, ntt = (n_own + 31) >> 5;
+    for (int tt0 = 0; tt0 < ntt && n_scan > 0; tt0 += 8) {
         const int tt = tt0 + wv;                               // wave-uniform
         const int j = tt * 32 + col;
-        const bool valid_t = tt < ntt && j < n2;
-        // B operand of the 8 K-steps: this lane's train descriptor, bits [32 s + 16 h, +16) of step s
+        const bool valid_t = tt < ntt && j < n_own;
+        // B operand of the 8 K-steps: this lane's own descriptor, bits [32 s + 16 h, +16) of step s
         v4i_t bop[8];
         int tpop = 0;
         {
@@ -210,23 +230,23 @@ __global__ __launch_bounds__(MM_NT) void match_hamming_mfma_kernel(const uint8_t
             for (int sK = 0; sK < 8; ++sK) { bop[sK] = expand16((tw[sK] >> (16 * h)) & 0xFFFFu); tpop += __popc(tw[sK]); }
         }
         unsigned best_key = 0xFFFFFFFFu;
-        // The raw query words are fetched MM_PF tiles ahead into a register ring: with a one-tile lookahead every step of
+        // The raw scanned words are fetched MM_PF tiles ahead into a register ring: with a one-tile lookahead every step of
         // the loop waited for an L2 round trip (diagnostic build: the loop without its MFMAs took 0.17 of the kernel's
         // 0.35 ms -- 128 steps of 1.3 us).  The loop is unrolled by MM_PF so that the ring is indexed statically.
         unsigned ring[MM_PF];
         auto fetch = [&](int qt) -> unsigned {
             const int q = qt * 32 + xrow;
-            return (qt < ntq && q < n1) ? q32[(long long)q * 8 + xs] : 0u;
+            return (qt < ntq && q < n_scan) ? q32[(long long)q * 8 + xs] : 0u;
         };
         auto stage = [&](int qt, int buf, unsigned raw) {
             s_a[(buf * 8 + xs) * 64 + xl] = expand16((raw >> (16 * xh)) & 0xFFFFu);
             if (tid < 32) {
                 const int qq = qt * 32 + tid;
-                const unsigned pk = qq < n1 ? (unsigned)s_qpop[qq] : 0x7000u;      // rows past n1: a key no real distance can beat
+                const unsigned pk = qq < n_scan ? (unsigned)s_qpop[qq] : 0x7000u;      // rows past the end: a key no real distance can beat
                 s_qpk[buf * 32 + tid] = (pk << 16) | (unsigned)qq;
             }
         };
-        __syncthreads();                                       // the previous pass has finished reading both buffers (and s_qpop is complete)
+        __syncthreads();                                       // the previous round has finished reading both buffers (and s_qpop is complete)
 #pragma unroll
         for (int u = 0; u < MM_PF; ++u) ring[u] = fetch(u);    // tiles 0 .. MM_PF - 1 in flight
         stage(0, 0, ring[0]);
@@ -247,11 +267,11 @@ __global__ __launch_bounds__(MM_NT) void match_hamming_mfma_kernel(const uint8_t
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const unsigned qpk = s_qpk[buf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
-                            best_key = min(best_key, (unsigned)__mul24(acc[r], -131072) + qpk);     // (|q| + 512 - 2 q.t) << 16 | queryIdx
+                            best_key = min(best_key, (unsigned)__mul24(acc[r], -131072) + qpk);     // (|x| + 512 - 2 x.own) << 16 | scannedIdx
                         }
                     }
                     if (qt + 1 < ntq) {
-                        // tile qt + 1 sits in ring slot (u + 1) % MM_PF (tile 0 of this pass was staged in the prologue)
+                        // tile qt + 1 sits in ring slot (u + 1) % MM_PF (tile 0 of this round was staged in the prologue)
                         stage(qt + 1, buf ^ 1, ring[(u + 1) % MM_PF]);
                         ring[(u + 1) % MM_PF] = fetch(qt + 1 + MM_PF);
                     }
@@ -262,8 +282,10 @@ __global__ __launch_bounds__(MM_NT) void match_hamming_mfma_kernel(const uint8_t
         best_key = min(best_key, (unsigned)__shfl_xor((int)best_key, 32));
         if (valid_t && h == 0) {
             const unsigned d = (best_key >> 16) - 512u + (unsigned)tpop, i = best_key & 0xFFFFu;
-            atomicMin(&s_best[i], (d << 18) | (unsigned)j);
+            if (pass == 0) atomicMin(&s_best[i], (d << 18) | (unsigned)j);      // train j elects query i
+            else s_row[j] = (d << 18) | i;                                      // query j's own nearest train i
         }
+    }
     }
     __syncthreads();
     // (dist, queryIdx) keys; unmatched queries sort to the end -- same epilogue as the VALU kernel
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(MM_NT) void match_hamming_mfma_kernel(const uint8_t
         unsigned key = 0xFFFFFFFFu;
         if (i < n1) {
             unsigned b = s_best[i];
-            if (b != 0xFFFFFFFFu) { key = ((b >> 18) << 16) | (unsigned)i; ++myvalid; }
+            if (b != 0xFFFFFFFFu && b == s_row[i]) { key = ((b >> 18) << 16) | (unsigned)i; ++myvalid; }
         }
         s_key[i] = key;
     }
@@ -309,7 +331,7 @@ __global__ __launch_bounds__(MM_NT) void match_hamming_mfma_kernel(const uint8_t
 void rpe_launch_match(rpe_handle *h, int B)
 {
     const int kcap = h->lay.kcap;
-    size_t lds = (size_t)QTILE * 32 + (size_t)kcap * 4;
+    size_t lds = (size_t)QTILE * 32 + (size_t)kcap * 8;       // staging / sort keys + election words + own-nearest words
     if (h->cfg.match_mode == RPE_MATCH_RATIO)
         hipLaunchKernelGGL((match_hamming_kernel<true>), dim3(B), dim3(256), lds, h->stream,
                            h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches, h->cfg.match_ratio,
@@ -318,10 +340,15 @@ void rpe_launch_match(rpe_handle *h, int B)
         hipLaunchKernelGGL((match_hamming_kernel<false>), dim3(B), dim3(256), lds, h->stream,
                            h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches, 0.0,
                            h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
-    else
-        hipLaunchKernelGGL(match_hamming_mfma_kernel, dim3(B), dim3(MM_NT), lds, h->stream,
-                           h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches,
+    else {
+        // first LDS region: max(staging 16 KB + 256 B of packed words + 2 B per scanned descriptor, 4 B x sort size)
+        int sortP = 64;
+        while (sortP < kcap) sortP <<= 1;
+        const size_t r0 = (std::max((size_t)(2 * 8 * 64 + 16) * 16 + (size_t)kcap * 2, (size_t)sortP * 4) + 15) / 16;
+        hipLaunchKernelGGL(match_hamming_mfma_kernel, dim3(B), dim3(MM_NT), r0 * 16 + (size_t)kcap * 8, h->stream,
+                           h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches, (int)r0,
                            h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
+    }
 }
 
 // ===================================================================== L2 (SIFT)
@@ -356,7 +383,10 @@ __device__ __forceinline__ unsigned dot_u8(const uint4 *q, const uint4 (&t)[NQ])
 // all query tiles; the election lands in HBM through a packed 64-bit atomicMin per query
 // (integer atomics: order independent).  Splitting a pair over its train chunks gives kcap/256 times
 // more workgroups than one workgroup per pair (32-pair HD sub-batches left 7/8 of the CUs idle).
-template <int NQ, bool RATIO>
+// MODE 0: crossCheck pass 0 (a lane owns a train and elects its nearest query: atomicMin into best[query]);
+// MODE 2: crossCheck pass 1 (a lane owns a query; its own nearest train goes to best[query], a plain store);
+// MODE 1: Lowe ratio (extension).
+template <int NQ, int MODE>
 __global__ __launch_bounds__(256) void match_l2_nearest_kernel(const uint8_t *__restrict__ desc, const int *__restrict__ kp_count,
                                                                 int img2_base, int kcap, double ratio, unsigned long long *__restrict__ best)
 {
@@ -366,12 +396,13 @@ __global__ __launch_bounds__(256) void match_l2_nearest_kernel(const uint8_t *__
     const int tid = threadIdx.x, pair = blockIdx.y, tc = blockIdx.x * 256;
     const int img1 = pair, img2 = img2_base + pair;
     const int n1 = min(kp_count[img1], kcap), n2 = min(kp_count[img2], kcap);
-    // crossCheck: a lane owns a train, queries stream through LDS; ratio (extension): a lane owns a query, trains stream
-    const int n_own = RATIO ? n1 : n2, n_scan = RATIO ? n2 : n1;
+    constexpr bool RATIO = MODE == 1, QOWN = MODE != 0;
+    // crossCheck pass 0: a lane owns a train, queries stream through LDS; pass 1 and ratio: a lane owns a query, trains stream
+    const int n_own = QOWN ? n1 : n2, n_scan = QOWN ? n2 : n1;
     if (tc >= n_own || n_scan <= 0) return;
     const uint4 *d1 = (const uint4 *)(desc + (long long)img1 * kcap * DIM);
     const uint4 *d2 = (const uint4 *)(desc + (long long)img2 * kcap * DIM);
-    const uint4 *d_own = RATIO ? d1 : d2, *d_scan = RATIO ? d2 : d1;
+    const uint4 *d_own = QOWN ? d1 : d2, *d_scan = QOWN ? d2 : d1;
     const int j = tc + tid;
     const bool valid = j < n_own;
     uint4 t[NQ];
@@ -415,21 +446,26 @@ __global__ __launch_bounds__(256) void match_l2_nearest_kernel(const uint8_t *__
             }
         }
     }
-    if (!RATIO) {
+    if (MODE == 0) {
         if (valid && besti >= 0)
             atomicMin(&best[(long long)pair * kcap + besti], ((unsigned long long)__float_as_uint(bestd) << 18) | (unsigned long long)j);
+    } else if (MODE == 2) {
+        if (valid && besti >= 0)
+            best[(long long)pair * kcap + j] = ((unsigned long long)__float_as_uint(bestd) << 18) | (unsigned long long)besti;
     } else if (valid && n_scan >= 2 && (double)bestd < ratio * (double)second) {
         best[(long long)pair * kcap + j] = ((unsigned long long)__float_as_uint(bestd) << 18) | (unsigned long long)besti;
     }
 }
 
 // Kernel 2: workgroup = pair: stable sort of the elected (distance, queryIdx) keys, first max_matches, point gather.
-__global__ __launch_bounds__(256) void match_l2_select_kernel(const unsigned long long *__restrict__ best, const int *__restrict__ kp_count,
+// best2 (crossCheck only, nullptr for the ratio mode): the query's own nearest train; the match survives iff the two keys are equal
+__global__ __launch_bounds__(256) void match_l2_select_kernel(const unsigned long long *__restrict__ best, const unsigned long long *__restrict__ best2,
+                                                               const int *__restrict__ kp_count,
                                                                const float2 *__restrict__ kp_pt, int img2_base, int kcap, int max_matches,
                                                                int *__restrict__ m_q, int *__restrict__ m_t, float *__restrict__ m_d,
                                                                int *__restrict__ m_n, float2 *__restrict__ pts1, float2 *__restrict__ pts2)
 {
-    extern __shared__ unsigned long long s_key[];          // sortP <= 4096 keys
+    extern __shared__ unsigned long long s_key[];          // sortP <= 8192 keys (64 KB)
     __shared__ int s_valid;
     const int tid = threadIdx.x, pair = blockIdx.x;
     const int img1 = pair, img2 = img2_base + pair;
@@ -444,7 +480,7 @@ __global__ __launch_bounds__(256) void match_l2_select_kernel(const unsigned lon
         unsigned long long key = ~0ull;
         if (i < n1) {
             unsigned long long b = bp[i];
-            if (b != ~0ull) { key = ((b >> 18) << 16) | (unsigned long long)i; ++myvalid; }
+            if (b != ~0ull && (!best2 || b == best2[(long long)pair * kcap + i])) { key = ((b >> 18) << 16) | (unsigned long long)i; ++myvalid; }
         }
         s_key[i] = key;
     }
@@ -481,15 +517,17 @@ void rpe_launch_match_l2(rpe_handle *h, int B)
     const int img2_base = h->img2_base ? h->img2_base : B;
     hipMemsetAsync(h->d_m_best, 0xFF, sizeof(unsigned long long) * (size_t)B * kcap, h->stream);
     const bool rt = h->cfg.match_mode == RPE_MATCH_RATIO;
+    if (!rt) hipMemsetAsync(h->d_m_best2, 0xFE, sizeof(unsigned long long) * (size_t)B * kcap, h->stream);
     const dim3 grid((kcap + 255) / 256, B);
-#define L2_LAUNCH(NQ, RT) hipLaunchKernelGGL((match_l2_nearest_kernel<NQ, RT>), grid, dim3(256), 0, h->stream, \
-                                             h->d_desc, h->d_kp_count, img2_base, kcap, h->cfg.match_ratio, h->d_m_best)
-    if (h->desc_bytes == 128) { if (rt) L2_LAUNCH(8, true); else L2_LAUNCH(8, false); }
-    else                      { if (rt) L2_LAUNCH(2, true); else L2_LAUNCH(2, false); }
+#define L2_LAUNCH(NQ, MODE, DST) hipLaunchKernelGGL((match_l2_nearest_kernel<NQ, MODE>), grid, dim3(256), 0, h->stream, \
+                                                    h->d_desc, h->d_kp_count, img2_base, kcap, h->cfg.match_ratio, DST)
+    if (h->desc_bytes == 128) { if (rt) L2_LAUNCH(8, 1, h->d_m_best); else { L2_LAUNCH(8, 0, h->d_m_best); L2_LAUNCH(8, 2, h->d_m_best2); } }
+    else                      { if (rt) L2_LAUNCH(2, 1, h->d_m_best); else { L2_LAUNCH(2, 0, h->d_m_best); L2_LAUNCH(2, 2, h->d_m_best2); } }
 #undef L2_LAUNCH
     int sortP = 64;
     while (sortP < kcap) sortP <<= 1;
     hipLaunchKernelGGL(match_l2_select_kernel, dim3(B), dim3(256), sizeof(unsigned long long) * (size_t)sortP, h->stream,
-                       (const unsigned long long *)h->d_m_best, h->d_kp_count, h->d_kp_pt, img2_base, kcap, h->cfg.max_matches,
+                       (const unsigned long long *)h->d_m_best, rt ? (const unsigned long long *)nullptr : (const unsigned long long *)h->d_m_best2,
+                       h->d_kp_count, h->d_kp_pt, img2_base, kcap, h->cfg.max_matches,
                        h->d_m_q, h->d_m_t, (float *)h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
 }

@@ -15,6 +15,7 @@
 // Everything is integer or mirrored-order f32, so results equal the CPU oracle bit for bit.
 #include "rpe_internal.h"
 #include "rpe_devmath.h"
+#include "retain_best_emul.h"
 
 #define TW 64
 #define TH 64
@@ -28,11 +29,9 @@ __constant__ signed char c_circ[16 * 2] = {0,3, 1,3, 2,2, 3,1, 3,0, 3,-1, 2,-2, 
 // .x = 1 per in-disc byte, .y = (u + 16) per in-disc byte (0 elsewhere)
 __constant__ uint2 c_discw[31 * 8];
 
-// B operand of the horizontal Gaussian pass as an i8 MFMA (orient_describe_kernel): [off0 0..3][K-step 0..1][column tile 0..1][lane]
-// 16 bytes each = T[32 s + 16 (lane >> 5) + b][32 nt + (lane & 31)], T[k][j] = tap[k - off0 - j]
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-typedef int v16i_t __attribute__((ext_vector_type(16)));
-__device__ v4i_t c_blur_b[4 * 2 * 2 * 64];
+// taps of the descriptor blur: GaussianBlur(7x7, sigma 2) as cv2's sepFilter2D f32 route holds them -- (float)(exp(-x^2 / 8) / sum),
+// getGaussianKernel's normalised f64 kernel cast to f32 (computed on the host at handle creation, like the oracle does)
+__constant__ float c_gauss[7];
 
 void rpe_orb_upload_disc(const signed char *disc, int n)
 {
@@ -55,25 +54,13 @@ void rpe_orb_upload_disc(const signed char *disc, int n)
         for (int i = 0; i < 1024; ++i) pf[i] = (float)pat[i];
         hipMemcpyToSymbol(HIP_SYMBOL(c_pattern_f), pf.data(), sizeof(float) * 1024);
     }
-    // banded tap matrix of the 7x7 Gaussian's horizontal pass, in MFMA B-operand order
-    static const signed char tap[7] = {18, 34, 49, 55, 49, 34, 18};
-    std::vector<signed char> tb((size_t)4 * 2 * 2 * 64 * 16, 0);
-    for (int off0 = 0; off0 < 4; ++off0)
-        for (int s = 0; s < 2; ++s)
-            for (int nt = 0; nt < 2; ++nt)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int b = 0; b < 16; ++b) {
-                        const int k = 32 * s + 16 * (lane >> 5) + b, j = 32 * nt + (lane & 31), d = k - off0 - j;
-                        signed char v = 0;
-                        if (k < 48 && d >= 0 && d <= 6) v = (signed char)tap[d];
-                        // rows 48..51 carry the +128 * 257 that undoes the signed-byte offset of the pixels: the A operand
-                        // holds (127, 127, 127, 1) there, 127 * (127 + 127 + 5) + 3 = 32896 (the C operand stays the constant 0)
-                        else if (k == 48 || k == 49) v = 127;
-                        else if (k == 50) v = 5;
-                        else if (k == 51) v = 3;
-                        tb[((((size_t)off0 * 2 + s) * 2 + nt) * 64 + lane) * 16 + b] = v;
-                    }
-    hipMemcpyToSymbol(HIP_SYMBOL(c_blur_b), tb.data(), tb.size());
+    {
+        double v[7], sum = 0.;
+        float g[7];
+        for (int i = 0; i < 7; ++i) { const double x = (double)(i - 3); v[i] = exp(-0.125 * x * x); sum += v[i]; }
+        for (int i = 0; i < 7; ++i) g[i] = (float)(v[i] / sum);
+        hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), g, sizeof(g));
+    }
 }
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an
@@ -516,51 +503,38 @@ __device__ __forceinline__ int block_excl_scan(int v, int *s_wave /*[5]*/, int &
 }
 
 // ----------------------------------------------------------------- select
-// KeyPointsFilter::retainBest(2*quota) on the FAST score: threshold tau = score of the (2q)-th best
-// keypoint, ties kept.  One workgroup per (image, level) reads the level's tile lists (twice; the second
-// pass hits L2) and emits the survivors in RASTER order (y, then x) -- the canonical order the oracle uses --
-// by a counting sort over rows in LDS:
-//   pass 1  per-row count of the entries with score >= tau (LDS atomics)       -> exclusive scan = row starts
+// cv2's keypoint ORDER (orb.cpp computeKeyPoints): FAST emits a level's corners in raster order, then
+// KeyPointsFilter::retainBest(2 * quota) on the FAST score reorders them through std::nth_element + std::partition;
+// the Harris responses are computed for the survivors in THAT order and retainBest(quota) reorders them once more.
+// The reference's own result rows pin this order (retain_best_emul.h, tests/test_reference_rows_cpu.py), so the
+// selection is replayed move for move:
+//   raster_corners  one workgroup per (level, image): the level's FAST tile lists -> ONE list in raster order
+//                   (counting sort over rows in LDS, rank by x inside a row), the first ccap entries
+//   retain_fast     one wave per (level, image), one lane working: retainBest(2 * quota) on the FAST score -> candidates
+//   harris          (below)
+//   retain_harris   one wave per (level, image): retainBest(quota) on the Harris response, in place
+//   compact         one workgroup per image: level-major concatenation into the keypoint arrays
+// Raster order, pass by pass:
+//   pass 1  per-row count of the entries (LDS atomics)                          -> exclusive scan = row starts
 //   pass 2  entry -> slot row_start[y] + (arrival order inside the row); rows that start at or beyond the
-//           candidate capacity are dropped here (their ranks are >= ccap whatever their x)
+//           capacity are dropped here (their ranks are >= ccap whatever their x)
 //   pass 3  rank inside the row by x (a row holds a handful of entries) -> final position; positions >= ccap
 //           are truncated exactly as the oracle truncates (first ccap in raster order) and flagged.
 // Arrival order inside a row depends on wave timing; the final position does not.
-__global__ __launch_bounds__(256) void select_candidates_kernel(const unsigned *__restrict__ tile_list, const int *__restrict__ tile_cnt,
-                                                                 const unsigned *__restrict__ hist,
-                                                                 unsigned *__restrict__ cand_xy, int *__restrict__ cand_count,
-                                                                 unsigned *__restrict__ ovf, RpeDeviceLayout lay, int ntiles, int rows_cap, int key_cap)
+__global__ __launch_bounds__(256) void raster_corners_kernel(const unsigned *__restrict__ tile_list, const int *__restrict__ tile_cnt,
+                                                              unsigned *__restrict__ corner, int *__restrict__ corner_count,
+                                                              unsigned *__restrict__ ovf, RpeDeviceLayout lay, int ntiles, int rows_cap, int key_cap)
 {
     extern __shared__ unsigned s_dyn[];
     unsigned *s_rs = s_dyn;                          // [rows_cap + 1] per-row counts, then exclusive row starts
     unsigned *s_fill = s_rs + rows_cap + 1;          // [rows_cap] arrival counters
-    unsigned *s_key = s_fill + rows_cap;             // [key_cap] staged y << 16 | x, grouped by row
+    unsigned *s_key = s_fill + rows_cap;             // [key_cap] staged entries (score << 24 | y << 12 | x), grouped by row
     unsigned *s_toff = s_key + key_cap;              // [level tiles + 1] exclusive prefix of the tile counts
     __shared__ int s_wave[5];
-    __shared__ int s_tau, s_live;
+    __shared__ int s_live;
     const int tid = threadIdx.x, l = blockIdx.x, img = blockIdx.y;
     const RpeLevel &L = lay.lv[l];
-    const unsigned *hg = hist + ((long long)img * RPE_NLEVELS + l) * 256;
     if (tid == 64) s_live = 0x7FFFFFFF;
-    if (tid < 64) {
-        // wave 0: suffix sums over 256 bins, 4 bins per lane (descending)
-        int b0 = 255 - 4 * tid;
-        int c0 = hg[b0], c1 = hg[b0 - 1], c2 = hg[b0 - 2], c3 = hg[b0 - 3];
-        int s = c0 + c1 + c2 + c3, inc = wave_inclusive_sum(s);
-        int total = __shfl(inc, 63);
-        int n2 = 2 * L.quota;
-        int before = inc - s;
-        // first bin (descending) where cumulative >= n2
-        int tau = -1;
-        if (before < n2 && inc >= n2) {
-            int a = before + c0;
-            if (a >= n2) tau = b0; else { a += c1; if (a >= n2) tau = b0 - 1; else { a += c2; tau = (a >= n2) ? b0 - 2 : b0 - 3; } }
-        }
-        unsigned long long m = __ballot(tau >= 0);
-        int src_lane = m ? (__ffsll((long long)m) - 1) : 0;
-        int t = __shfl(tau, src_lane);
-        if (tid == 0) s_tau = (total > n2 && m) ? max(t, 1) : 1;
-    }
     const int nrows = L.h, nt = L.ntile, ccap = L.ccap;
     for (int i = tid; i <= nrows; i += 256) s_rs[i] = 0;
     for (int i = tid; i < nrows; i += 256) s_fill[i] = 0;
@@ -578,7 +552,6 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const unsigned *
     }
     if (tid == 0) s_toff[nt] = (unsigned)nraw;
     __syncthreads();
-    const unsigned tau = (unsigned)s_tau;
     // entry s of the concatenated lists -> (tile, index) by binary search over the prefix
     auto fetch = [&](int sidx) -> unsigned {
         int lo = 0, hi = nt;                               // s_toff[lo] <= sidx < s_toff[hi]
@@ -586,13 +559,13 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const unsigned *
         return tl[(long long)lo * RPE_FAST_TILE_CAP + (sidx - (int)s_toff[lo])];
     };
     // both passes over the lists take four entries per lane and round: four independent loads in flight instead of one
-    // dependent L2 / HBM round trip per 256 entries (the kernel is a chain of such round trips: 0.19 ms for 0.08 G instructions)
+    // dependent L2 / HBM round trip per 256 entries
     for (int base = 0; base < nraw; base += 1024) {
         unsigned e4[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int sidx = base + tid + 256 * u; e4[u] = sidx < nraw ? fetch(sidx) : 0u; }   // score 0 < tau
+        for (int u = 0; u < 4; ++u) { const int sidx = base + tid + 256 * u; e4[u] = sidx < nraw ? fetch(sidx) : 0u; }   // score 0 = no entry
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if ((e4[u] >> 24) >= tau) atomicAdd(&s_rs[(e4[u] >> 12) & 0xFFFu], 1u);
+        for (int u = 0; u < 4; ++u) if (e4[u] >> 24) atomicAdd(&s_rs[(e4[u] >> 12) & 0xFFFu], 1u);
     }
     __syncthreads();
     // exclusive scan of the row counts, 16 consecutive rows per lane
@@ -622,48 +595,99 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const unsigned *
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const unsigned e = e4[u];
-            if ((e >> 24) >= tau) {
+            if (e >> 24) {
                 const unsigned y = (e >> 12) & 0xFFFu, rs = s_rs[y];
                 if (rs < (unsigned)ccap) {
                     const unsigned slot = rs + atomicAdd(&s_fill[y], 1u);
-                    if (slot < (unsigned)key_cap) s_key[slot] = (y << 16) | (e & 0xFFFu);
+                    if (slot < (unsigned)key_cap) s_key[slot] = e;
                 }
             }
         }
     }
     __syncthreads();
-    unsigned *out = cand_xy + (long long)img * lay.cand_total + L.cand_off;
+    unsigned *out = corner + (long long)img * lay.corner_total + L.corner_off;
     // staged slots: every row that starts below ccap is staged whole, so the live slots are [0, first row start >= ccap)
     // (or all `kept` of them); a row holds <= w/2 keypoints, hence nlive <= ccap + w/2 <= key_cap
     const int nlive = min(min(s_live, kept), key_cap);
     for (int slot = tid; slot < nlive; slot += 256) {
         const unsigned key = s_key[slot];
-        const unsigned y = key >> 16, x = key & 0xFFFFu;
+        const unsigned y = (key >> 12) & 0xFFFu, x = key & 0xFFFu;
         const unsigned rs = s_rs[y], re = s_rs[y + 1];
         unsigned rank = 0;
-        for (unsigned j = rs; j < re; ++j) rank += ((s_key[j] & 0xFFFFu) < x) ? 1u : 0u;
+        for (unsigned j = rs; j < re; ++j) rank += ((s_key[j] & 0xFFFu) < x) ? 1u : 0u;
         const unsigned pos = rs + rank;
         if (pos < (unsigned)ccap) out[pos] = key;
     }
     if (tid == 0) {
-        cand_count[img * RPE_NLEVELS + l] = min(kept, ccap);
+        corner_count[img * RPE_NLEVELS + l] = min(kept, ccap);
         if (kept > ccap) atomicOr(&ovf[img], (unsigned)RPE_OVF_ORB_CANDIDATES);
     }
 }
 
+// retainBest(2 * quota) on the FAST score.  One wave per (level, image); the list sits in LDS and ONE lane replays the
+// runtime library's nth_element + partition on it (retain_best_emul.h) -- the algorithm is a chain of data-dependent
+// swaps, there is nothing for the other 63 lanes to do but the copies in and out.  Two launches share the work by list
+// length (lo < n0 <= cap) so that the common short lists do not reserve the LDS of the longest possible one.
+struct FastScoreGT { __device__ __forceinline__ bool operator()(unsigned a, unsigned b) const { return (a >> 24) > (b >> 24); } };
+struct FastScoreGE { __device__ __forceinline__ bool operator()(unsigned a, unsigned b) const { return (a >> 24) >= (b >> 24); } };
+
+__global__ __launch_bounds__(64) void retain_fast_kernel(const unsigned *__restrict__ corner, const int *__restrict__ corner_count,
+                                                          unsigned *__restrict__ cand_xy, int *__restrict__ cand_count,
+                                                          unsigned *__restrict__ ovf, RpeDeviceLayout lay, int lo, int cap)
+{
+    extern __shared__ unsigned s_a[];
+    __shared__ int s_n1;
+    const int lane = threadIdx.x, l = blockIdx.x, img = blockIdx.y;
+    const RpeLevel &L = lay.lv[l];
+    const int n0 = corner_count[img * RPE_NLEVELS + l];
+    const int n_points = 2 * L.quota;
+    const bool active = n0 > n_points;                       // retainBest does nothing otherwise (the list stays in raster order)
+    // the pass-through lists belong to the first launch (lo == 0)
+    if (active ? !(n0 > lo && n0 <= cap) : lo != 0) return;
+    const unsigned *in = corner + (long long)img * lay.corner_total + L.corner_off;
+    unsigned *out = cand_xy + (long long)img * lay.cand_total + L.cand_off;
+    int n1 = n0;
+    if (active) {
+        for (int i = lane; i < n0; i += 64) s_a[i] = in[i];
+        __syncthreads();
+        if (lane == 0) s_n1 = rb::retain_best(s_a, n0, n_points, lay.stl, FastScoreGT(), FastScoreGE());
+        __syncthreads();
+        n1 = s_n1;
+    }
+    const int nw = min(n1, L.kcap2);
+    for (int i = lane; i < nw; i += 64) {
+        const unsigned e = active ? s_a[i] : in[i];
+        out[i] = (((e >> 12) & 0xFFFu) << 16) | (e & 0xFFFu);
+    }
+    if (lane == 0) {
+        cand_count[img * RPE_NLEVELS + l] = nw;
+        if (n1 > L.kcap2) atomicOr(&ovf[img], (unsigned)RPE_OVF_ORB_CANDIDATES);
+    }
+}
+
+#define RPE_RETAIN_TIER 2048         // list length served by the small-LDS launch of the two retain kernels
+
 void rpe_launch_select(rpe_handle *h, int n_img)
 {
-    // LDS: row starts + fill counters + staged keys (capacity: largest ccap + one full row of keypoints) + tile prefix
-    int rows_cap = 0, ccap_max = 0, nt_max = 0, wmax = 0;
+    // LDS: row starts + fill counters + staged entries (capacity: largest ccap + one full row of keypoints) + tile prefix
+    int rows_cap = 0, ccap_max = 0, nt_max = 0, wmax = 0, nlev_big = 0;
     for (int l = 0; l < RPE_NLEVELS; ++l) {
         rows_cap = std::max(rows_cap, h->lay.lv[l].h); ccap_max = std::max(ccap_max, h->lay.lv[l].ccap);
         nt_max = std::max(nt_max, h->lay.lv[l].ntile); wmax = std::max(wmax, h->lay.lv[l].w);
+        if (h->lay.lv[l].ccap > RPE_RETAIN_TIER) nlev_big = l + 1;       // capacities shrink with the level
     }
     const int key_cap = ccap_max + wmax / 2 + 64;
     const size_t lds = sizeof(unsigned) * ((size_t)rows_cap + 1 + rows_cap + key_cap + nt_max + 1);
-    hipLaunchKernelGGL(select_candidates_kernel, dim3(RPE_NLEVELS, n_img), dim3(256), lds, h->stream,
-                       (const unsigned *)h->d_tile_list, (const int *)h->d_tile_cnt, (const unsigned *)h->d_hist,
-                       h->d_cand_xy, h->d_cand_count, h->d_ovf, h->lay, h->n_tiles_fast, rows_cap, key_cap);
+    hipLaunchKernelGGL(raster_corners_kernel, dim3(RPE_NLEVELS, n_img), dim3(256), lds, h->stream,
+                       (const unsigned *)h->d_tile_list, (const int *)h->d_tile_cnt,
+                       h->d_corner, h->d_corner_count, h->d_ovf, h->lay, h->n_tiles_fast, rows_cap, key_cap);
+    hipLaunchKernelGGL(retain_fast_kernel, dim3(RPE_NLEVELS, n_img), dim3(64), sizeof(unsigned) * (size_t)std::min(ccap_max, RPE_RETAIN_TIER), h->stream,
+                       (const unsigned *)h->d_corner, (const int *)h->d_corner_count, h->d_cand_xy, h->d_cand_count, h->d_ovf, h->lay,
+                       0, std::min(ccap_max, RPE_RETAIN_TIER));
+    if (nlev_big > 0)
+        hipLaunchKernelGGL(retain_fast_kernel, dim3(nlev_big, n_img), dim3(64), sizeof(unsigned) * (size_t)ccap_max, h->stream,
+                           (const unsigned *)h->d_corner, (const int *)h->d_corner_count, h->d_cand_xy, h->d_cand_count, h->d_ovf, h->lay,
+                           RPE_RETAIN_TIER, ccap_max);
 }
 
 // ----------------------------------------------------------------- harris
@@ -740,109 +764,86 @@ void rpe_launch_harris(rpe_handle *h, int n_img)
 }
 
 // -------------------------------------------------------------- keypoints
-// KeyPointsFilter::retainBest(quota) on the Harris response per level (radix
-// select of the quota-th largest f32, ties kept), ordered compaction into the
-// final level-major / raster-ordered keypoint list.  One workgroup per image.
-__device__ __forceinline__ unsigned float_key(float f)
+// KeyPointsFilter::retainBest(quota) on the Harris response, per level, replayed on the candidates in the order the
+// first retainBest left them (see "select" above): element = (f32 response bits << 32 | y << 16 | x), one lane, in LDS;
+// the survivors go back to the head of the level's candidate run, in order.  compact_keypoints then concatenates the
+// levels into the level-major keypoint arrays the descriptor kernel and the matcher read.
+struct HarrisGT { __device__ __forceinline__ bool operator()(unsigned long long a, unsigned long long b) const { return __uint_as_float((unsigned)(a >> 32)) > __uint_as_float((unsigned)(b >> 32)); } };
+struct HarrisGE { __device__ __forceinline__ bool operator()(unsigned long long a, unsigned long long b) const { return __uint_as_float((unsigned)(a >> 32)) >= __uint_as_float((unsigned)(b >> 32)); } };
+
+__global__ __launch_bounds__(64) void retain_harris_kernel(unsigned *__restrict__ cand_xy, float *__restrict__ cand_resp,
+                                                            const int *__restrict__ cand_count, int *__restrict__ kp_lvl_count,
+                                                            RpeDeviceLayout lay, int lo, int cap)
 {
-    unsigned u = __float_as_uint(f);
-    if (u == 0x80000000u) u = 0;
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    extern __shared__ unsigned long long s_e[];
+    __shared__ int s_n2;
+    const int lane = threadIdx.x, l = blockIdx.x, img = blockIdx.y;
+    const RpeLevel &L = lay.lv[l];
+    const int n1 = cand_count[img * RPE_NLEVELS + l];
+    const int q = L.quota;
+    const bool active = n1 > q;
+    if (active ? !(n1 > lo && n1 <= cap) : lo != 0) return;
+    if (!active) { if (lane == 0) kp_lvl_count[img * RPE_NLEVELS + l] = n1; return; }
+    unsigned *xy = cand_xy + (long long)img * lay.cand_total + L.cand_off;
+    float *resp = cand_resp + (long long)img * lay.cand_total + L.cand_off;
+    for (int i = lane; i < n1; i += 64) s_e[i] = ((unsigned long long)__float_as_uint(resp[i]) << 32) | xy[i];
+    __syncthreads();
+    if (lane == 0) s_n2 = rb::retain_best(s_e, n1, q, lay.stl, HarrisGT(), HarrisGE());
+    __syncthreads();
+    const int n2 = s_n2;
+    for (int i = lane; i < n2; i += 64) { const unsigned long long e = s_e[i]; xy[i] = (unsigned)e; resp[i] = __uint_as_float((unsigned)(e >> 32)); }
+    if (lane == 0) kp_lvl_count[img * RPE_NLEVELS + l] = n2;
 }
 
-// One workgroup per image, one WAVE per pyramid level: the 12 radix selects run side by side
-// (the first version walked the levels one after the other with a serial 256-bin scan per pass and
-// was pure latency).  Per level: 4 radix passes over the order-preserving keys (LDS histogram per
-// wave, descending bin scan with 4 bins per lane + wave prefix sum), count of survivors, then --
-// once every level's count is known -- raster-ordered compaction by ballot at the level's offset.
-// All waves execute the same number of barriers (levels with n <= quota run the passes too and
-// ignore the result).
-__global__ __launch_bounds__(64 * RPE_NLEVELS) void select_keypoints_kernel(const unsigned *__restrict__ cand_xy, const float *__restrict__ cand_resp,
-                                                                             const int *__restrict__ cand_count,
-                                                                             unsigned *__restrict__ kp_xy, float *__restrict__ kp_resp,
-                                                                             float2 *__restrict__ kp_pt, int *__restrict__ kp_count,
-                                                                             unsigned *__restrict__ ovf, RpeDeviceLayout lay)
+__global__ __launch_bounds__(256) void compact_keypoints_kernel(const unsigned *__restrict__ cand_xy, const float *__restrict__ cand_resp,
+                                                                 const int *__restrict__ kp_lvl_count,
+                                                                 unsigned *__restrict__ kp_xy, float *__restrict__ kp_resp,
+                                                                 float2 *__restrict__ kp_pt, int *__restrict__ kp_count,
+                                                                 unsigned *__restrict__ ovf, RpeDeviceLayout lay)
 {
-    __shared__ unsigned s_hist[RPE_NLEVELS][256];
-    __shared__ int s_cnt[RPE_NLEVELS];
-    const int lane = threadIdx.x & 63, l = threadIdx.x >> 6, img = blockIdx.x;
-    const int kcap = lay.kcap;
-    const RpeLevel &L = lay.lv[l];
-    const int n = cand_count[img * RPE_NLEVELS + l];
-    const int q = L.quota;
-    const float *resp = cand_resp + (long long)img * lay.cand_total + L.cand_off;
-    const unsigned *xy = cand_xy + (long long)img * lay.cand_total + L.cand_off;
-    unsigned *hist = s_hist[l];
-    unsigned prefix = 0, mask = 0;
-    int kk = q;
-    for (int pass = 3; pass >= 0; --pass) {
-        const int shift = 8 * pass;
-        hist[lane] = 0; hist[lane + 64] = 0; hist[lane + 128] = 0; hist[lane + 192] = 0;
-        __syncthreads();
-        for (int i = lane; i < n; i += 64) {
-            const unsigned key = float_key(resp[i]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
-        }
-        __syncthreads();
-        // first bin (descending) where the running count reaches kk
-        const int b0 = 255 - 4 * lane;
-        const int c0 = (int)hist[b0], c1 = (int)hist[b0 - 1], c2 = (int)hist[b0 - 2], c3 = (int)hist[b0 - 3];
-        const int sum = c0 + c1 + c2 + c3;
-        const int inc = wave_inclusive_sum(sum);
-        const int before = inc - sum;
-        int fb = -1, fa = 0;
-        if (before < kk && inc >= kk) {
-            int a = before;
-            if (a + c0 >= kk) { fb = b0; fa = a; }
-            else { a += c0; if (a + c1 >= kk) { fb = b0 - 1; fa = a; }
-                   else { a += c1; if (a + c2 >= kk) { fb = b0 - 2; fa = a; } else { a += c2; fb = b0 - 3; fa = a; } } }
-        }
-        const unsigned long long bm = __ballot(fb >= 0);
-        const int srcl = bm ? (__ffsll((long long)bm) - 1) : 0;
-        const int bin = max(__shfl(fb, srcl), 0), acc = __shfl(fa, srcl);
-        kk -= acc;
-        prefix |= (unsigned)bin << shift;
-        mask |= 255u << shift;
-        __syncthreads();
-    }
-    const unsigned thr_key = (n > q) ? prefix : 0u;
-    int cnt = 0;
-    for (int i = lane; i < n; i += 64) cnt += float_key(resp[i]) >= thr_key;
-    cnt = wave_sum(cnt);
-    if (lane == 0) s_cnt[l] = cnt;
-    __syncthreads();
-    int offset = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < RPE_NLEVELS; ++k) { const int c = s_cnt[k]; if (k < l) offset += c; total += c; }
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        const int i = c0 + lane;
-        float r = 0.f; bool keep = false;
-        if (i < n) { r = resp[i]; keep = float_key(r) >= thr_key; }
-        const unsigned long long km = __ballot(keep);
-        if (keep) {
-            const int o = offset + __popcll(km & ((1ull << lane) - 1ull));
+    const int img = blockIdx.x, kcap = lay.kcap;
+    int offset = 0;
+#pragma unroll 1
+    for (int l = 0; l < RPE_NLEVELS; ++l) {
+        const RpeLevel &L = lay.lv[l];
+        const int n = kp_lvl_count[img * RPE_NLEVELS + l];
+        const unsigned *xy = cand_xy + (long long)img * lay.cand_total + L.cand_off;
+        const float *resp = cand_resp + (long long)img * lay.cand_total + L.cand_off;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int o = offset + i;
             if (o < kcap) {
                 const unsigned p = xy[i];
                 const int x = p & 0xFFFF, y = p >> 16;
                 const long long g = (long long)img * kcap + o;
                 kp_xy[g] = (unsigned)x | ((unsigned)y << 12) | ((unsigned)l << 24);
-                kp_resp[g] = r;
+                kp_resp[g] = resp[i];
                 kp_pt[g] = make_float2((float)x * L.scale, (float)y * L.scale);
             }
         }
-        offset += __popcll(km);
+        offset += n;
     }
     if (threadIdx.x == 0) {
-        kp_count[img] = min(total, kcap);
-        if (total > kcap) atomicOr(&ovf[img], (unsigned)RPE_OVF_ORB_KEYPOINTS);
+        kp_count[img] = min(offset, kcap);
+        if (offset > kcap) atomicOr(&ovf[img], (unsigned)RPE_OVF_ORB_KEYPOINTS);
     }
 }
 
 void rpe_launch_keypoints(rpe_handle *h, int n_img)
 {
-    hipLaunchKernelGGL(select_keypoints_kernel, dim3(n_img), dim3(64 * RPE_NLEVELS), 0, h->stream,
-                       h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_pt,
-                       h->d_kp_count, h->d_ovf, h->lay);
+    int kcap2_max = 0, nlev_big = 0;
+    for (int l = 0; l < RPE_NLEVELS; ++l) {
+        kcap2_max = std::max(kcap2_max, h->lay.lv[l].kcap2);
+        if (h->lay.lv[l].kcap2 > RPE_RETAIN_TIER / 2) nlev_big = l + 1;
+    }
+    const int tier = std::min(kcap2_max, RPE_RETAIN_TIER / 2);
+    hipLaunchKernelGGL(retain_harris_kernel, dim3(RPE_NLEVELS, n_img), dim3(64), sizeof(unsigned long long) * (size_t)tier, h->stream,
+                       h->d_cand_xy, h->d_cand_resp, (const int *)h->d_cand_count, h->d_kp_lvl_count, h->lay, 0, tier);
+    if (nlev_big > 0)
+        hipLaunchKernelGGL(retain_harris_kernel, dim3(nlev_big, n_img), dim3(64), sizeof(unsigned long long) * (size_t)kcap2_max, h->stream,
+                           h->d_cand_xy, h->d_cand_resp, (const int *)h->d_cand_count, h->d_kp_lvl_count, h->lay, RPE_RETAIN_TIER / 2, kcap2_max);
+    hipLaunchKernelGGL(compact_keypoints_kernel, dim3(n_img), dim3(256), 0, h->stream,
+                       (const unsigned *)h->d_cand_xy, (const float *)h->d_cand_resp, (const int *)h->d_kp_lvl_count,
+                       h->d_kp_xy, h->d_kp_resp, h->d_kp_pt, h->d_kp_count, h->d_ovf, h->lay);
 }
 
 // ------------------------------------------------- orientation + descriptor
@@ -863,19 +864,16 @@ void rpe_launch_keypoints(rpe_handle *h, int n_img)
 #define KP_R 22
 #define KP_ROWS 45
 #define KP_RAW_DW 12                 // 48 bytes per raw row
-#define KP_HCOLS 40                  // horizontally blurred columns: x = x0 - 19 + j
-#define KP_HROWS 48                  // rows per column of the blurred buffer (45 + 3 of padding for the unpredicated MFMA tile stores)
-#define KP_HSTRIDE 52                // u16 per column (104 B: 48 rows + 8 B; 26 dwords, so the 16 lanes of a ds_write_b64 group hit 16 distinct bank pairs)
+#define KP_HCOLS 40                  // horizontally blurred columns: x = x0 - 19 + j (the descriptor reaches |dx| <= 18: columns 1..37)
+#define KP_HSTRIDE 49                // f32 per column of the blurred buffer (45 rows + padding; odd, so neighbouring columns start in different banks)
 __global__ __launch_bounds__(64 * KP_PER_WG) void orient_describe_kernel(const uint8_t *__restrict__ pyr, const unsigned *__restrict__ kp_xy,
                                                                const float2 *__restrict__ kp_pt, const int *__restrict__ kp_count,
                                                                float *__restrict__ kp_angle, uint8_t *__restrict__ desc,
                                                                RpeDeviceLayout lay, int nb, int n_img)
 {
-    __shared__ __attribute__((aligned(16))) unsigned s_raw[KP_PER_WG][KP_ROWS * KP_RAW_DW];   // 2160 B per wave: 16-B aligned rows of 48 B
-    // horizontally blurred patch, COLUMN-major u16 [column][row]: the 7 vertical taps of a steered sample are 14
-    // contiguous bytes (three aligned ds_read_b64 instead of seven bank-conflicting ds_read_u16), and an MFMA lane, which
-    // owns one column and 4 consecutive rows per register group, stores 8 bytes at a time
-    __shared__ __attribute__((aligned(8))) unsigned s_hb[KP_PER_WG][KP_HCOLS * KP_HSTRIDE / 2];
+    __shared__ __attribute__((aligned(16))) unsigned s_raw[KP_PER_WG][KP_ROWS * KP_RAW_DW + 4];   // 16-B aligned rows of 48 B (+ one row pass over-read)
+    // horizontally blurred patch, COLUMN-major f32 [column][row]: the 7 vertical taps of a steered sample are contiguous
+    __shared__ float s_hb[KP_PER_WG][KP_HCOLS * KP_HSTRIDE];
 #if KP_PER_WG > 1
     __shared__ int s_m[KP_PER_WG][2];              // (m01, m10) of the workgroup's keypoints
     __shared__ float s_ab[KP_PER_WG][2];           // (cos, sin) of their angles
@@ -893,7 +891,8 @@ __global__ __launch_bounds__(64 * KP_PER_WG) void orient_describe_kernel(const u
     const RpeLevel &L = lay.lv[l];
     const int pitch = L.pitch;
     const int xal = (x0 - KP_R) & ~3, off0 = (x0 - KP_R) - xal;     // off0 in 0..3
-    unsigned *raw = s_raw[wv], *hb = s_hb[wv];
+    unsigned *raw = s_raw[wv];
+    float *hb = s_hb[wv];
     if (active) {
         const uint8_t *src = rpe_level_base(pyr, lay, img, l) + (long long)(y0 - KP_R) * pitch + xal;
         // lane -> fixed dword column (lane % 12) and rows lane / 12 + 5 q (60 lanes x 9 loads = 45 x 12 dwords)
@@ -943,50 +942,40 @@ __global__ __launch_bounds__(64 * KP_PER_WG) void orient_describe_kernel(const u
 #else
         km01 = m01; km10 = m10;
 #endif
-        // ---- horizontal pass on the matrix cores: hbuf column j <-> x = x0 - 19 + j (40 per row; the descriptor reaches
-        // |dx| <= 18).  H[45 x 40] = P[45 x 48 raw bytes] . T[48 x 40] with the banded tap matrix T[k][j] = tap[k - off0 - j]
-        // (tap = cvRound(256 g) = 18,34,49,55,49,34,18): 2 x 2 output tiles x 2 K-steps of v_mfma_i32_32x32x32_i8, exact
-        // integers.  The u8 pixels enter as signed bytes (p - 128, one v_xor per dword); the tap sum's share of the offset,
-        // 128 * 257, comes back through four spare K rows (see rpe_orb_upload_disc), so the C operand is the constant 0.
-        // The pass used to be 430 items x ~33 vector instructions (two v_dot4 per output plus the byte alignment) = 30 % of
-        // this kernel's instructions; now the vector ALU only flips the sign bits.  Accumulators go to the column-major LDS
-        // buffer as u16 (<= 65535 = 255 * 257), four rows per ds_write_b64.
+        // ---- horizontal pass of the descriptor blur.  cv2 blurs every pyramid level with GaussianBlur(7x7, sigma 2) before
+        // computeOrbDescriptors; on a pyramid SUB-matrix that call takes sepFilter2D's f32 route (filter.simd.hpp
+        // RowFilter<uchar, float>, SymmColumnFilter<Cast<float, uchar>>), whose AVX2-dispatched build fuses s += f * x: the
+        // reference's own result rows single this out against every fixed-point variant (tests/test_reference_rows_cpu.py).
+        // Row pass: s = g0 p[x-3]; s = fma(g_k, p[x-3+k], s), k = 1..6, in that order.  hbuf column j <-> x = x0 - 19 + j.
+        // Item = (patch row, group of 8 columns): 45 x 5 items, 20 raw bytes each, shared by the item's 8 outputs.
         {
-            const int hh = lane >> 5, c32 = lane & 31;
-            const uint8_t *rawb = (const uint8_t *)raw;
-            unsigned short *hb16 = (unsigned short *)hb;
-            v4i_t bop[2][2];
+            const float g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];
 #pragma unroll
-            for (int sK = 0; sK < 2; ++sK)
+            for (int q = 0; q < 4; ++q) {
+                const int it = lane + 64 * q;
+                if (it < KP_ROWS * 5) {
+                    const int row = it / 5, cg = it - 5 * row;
+                    const unsigned *pw = raw + row * KP_RAW_DW + 2 * cg;
+                    const unsigned d0 = pw[0], d1 = pw[1], d2 = pw[2], d3 = pw[3], d4 = pw[4];
+                    const unsigned q0 = __builtin_amdgcn_alignbyte(d1, d0, off0), q1 = __builtin_amdgcn_alignbyte(d2, d1, off0),
+                                   q2 = __builtin_amdgcn_alignbyte(d3, d2, off0), q3 = __builtin_amdgcn_alignbyte(d4, d3, off0);
+                    float f[16];
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) bop[sK][nt] = c_blur_b[((off0 * 2 + sK) * 2 + nt) * 64 + lane];
-            const v16i_t czero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // C operand: the inline constant 0
+                    for (int e = 0; e < 4; ++e) {
+                        f[e] = (float)((q0 >> (8 * e)) & 255u); f[4 + e] = (float)((q1 >> (8 * e)) & 255u);
+                        f[8 + e] = (float)((q2 >> (8 * e)) & 255u); f[12 + e] = (float)((q3 >> (8 * e)) & 255u);
+                    }
+                    float *dst = hb + (8 * cg) * KP_HSTRIDE + row;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int arow = min(32 * mt + c32, KP_ROWS - 1);
-                v4i_t a0 = *(const v4i_t *)(rawb + arow * (KP_RAW_DW * 4) + 16 * hh);          // K-step 0: row bytes [16 hh, +16)
-                v4i_t a1 = {(int)(0x017F7F7Fu ^ 0x80808080u), (int)0x80808080, (int)0x80808080, (int)0x80808080};   // K-step 1, k = 48..63: (127, 127, 127, 1, 0 ...) after the sign flip below
-                if (hh == 0) a1 = *(const v4i_t *)(rawb + arow * (KP_RAW_DW * 4) + 32);        // K-step 1: row bytes [32, 48)
-                a0 ^= (int)0x80808080; a1 ^= (int)0x80808080;
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    v16i_t acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bop[0][nt], czero, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bop[1][nt], acc, 0, 0, 0);
-                    const int colj = 32 * nt + c32;
-                    if (colj < KP_HCOLS) {
-                        // C layout: registers 4 g .. 4 g + 3 hold rows 8 g + 4 hh .. + 3 of the tile, this lane's column:
-                        // four u16 = one ds_write_b64 per group (rows 45..47 exist as padding, groups from row 48 on are
-                        // skipped statically)
-                        unsigned short *dst = hb16 + colj * KP_HSTRIDE + 32 * mt + 4 * hh;
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) {
-                            if (32 * mt + 8 * gq + 4 < KP_HROWS) {
-                                uint2 pk;
-                                pk.x = __builtin_amdgcn_perm((unsigned)acc[4 * gq + 1], (unsigned)acc[4 * gq], 0x05040100u);      // low halves of two accumulators
-                                pk.y = __builtin_amdgcn_perm((unsigned)acc[4 * gq + 3], (unsigned)acc[4 * gq + 2], 0x05040100u);
-                                *(uint2 *)(dst + 8 * gq) = pk;
-                            }
-                        }
+                    for (int o = 0; o < 8; ++o) {
+                        float sacc = g0 * f[o];
+                        sacc = __builtin_fmaf(g1, f[o + 1], sacc);
+                        sacc = __builtin_fmaf(g2, f[o + 2], sacc);
+                        sacc = __builtin_fmaf(g3, f[o + 3], sacc);
+                        sacc = __builtin_fmaf(g2, f[o + 4], sacc);      // the kernel is symmetric: g4 = g2, g5 = g1, g6 = g0 (same f32 values)
+                        sacc = __builtin_fmaf(g1, f[o + 5], sacc);
+                        sacc = __builtin_fmaf(g0, f[o + 6], sacc);
+                        dst[o * KP_HSTRIDE] = sacc;
                     }
                 }
             }
@@ -1019,13 +1008,11 @@ __global__ __launch_bounds__(64 * KP_PER_WG) void orient_describe_kernel(const u
     }
 #endif
     // ---- orb.cpp computeOrbDescriptors: lane = 4 consecutive bit tests, vertical pass at the samples
-    const uint8_t *hbytes = (const uint8_t *)hb;
     const float2 pt = kp_pt[g];
     const float sc = 1.f / L.scale;
     const int cx = __float2int_rn(pt.x * sc), cy = __float2int_rn(pt.y * sc);
     const int dxo = cx - x0 + 19, dyo = cy - y0 + KP_R - 3;       // (cx,cy) == (x0,y0) in practice
-    typedef unsigned short v2u16_t __attribute__((ext_vector_type(2)));
-    const v2u16_t T01 = {18, 34}, T23 = {49, 55}, T45 = {49, 34}, T6 = {18, 0};
+    const float g3 = c_gauss[3], g4 = c_gauss[4], g5 = c_gauss[5], g6 = c_gauss[6];
     unsigned nib = 0;
 #pragma unroll
     for (int bit = 0; bit < 4; ++bit) {
@@ -1033,24 +1020,18 @@ __global__ __launch_bounds__(64 * KP_PER_WG) void orient_describe_kernel(const u
         const float p0 = pf.x, p1 = pf.y, p2 = pf.z, p3 = pf.w;
         float fx0 = p0 * a - p1 * b, fy0 = p0 * b + p1 * a;
         float fx1 = p2 * a - p3 * b, fy1 = p2 * b + p3 * a;
-        int t01[2];
+        float t01[2];
         const int ixs[2] = {__float2int_rn(fx0), __float2int_rn(fx1)}, iys[2] = {__float2int_rn(fy0), __float2int_rn(fy1)};
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            // the 7 vertical taps = rows iy + dyo .. + 6 of column ix + dxo: 14 contiguous bytes at an even offset: the four
-            // dwords from the one holding the first tap cover them (2 + 14 = 16); shift by the half-word phase, four
-            // v_dot2_u32_u16 against the tap pairs (the 8th half-word meets a zero tap)
-            const int addr = (ixs[e] + dxo) * (KP_HSTRIDE * 2) + (iys[e] + dyo) * 2;
-            const unsigned *wp = (const unsigned *)(hbytes + (addr & ~3));
-            const unsigned a0 = wp[0], a1 = wp[1], a2 = wp[2], a3 = wp[3];
-            const unsigned sh = addr & 2;
-            const unsigned q0 = __builtin_amdgcn_alignbyte(a1, a0, sh), q1 = __builtin_amdgcn_alignbyte(a2, a1, sh),
-                           q2 = __builtin_amdgcn_alignbyte(a3, a2, sh), q3 = __builtin_amdgcn_alignbyte(0u, a3, sh);
-            unsigned s = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, q0), T01, 32768u, false);
-            s = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, q1), T23, s, false);
-            s = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, q2), T45, s, false);
-            s = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_t, q3), T6, s, false);
-            t01[e] = (int)min(s >> 16, 255u);                          // FixedPtCastEx<int, uchar> saturates (taps sum to 257)
+            // vertical pass at the sample only: the 7 taps = rows iy + dyo .. + 6 of column ix + dxo, contiguous f32;
+            // s = g3 c; s = fma(g_{3+k}, t[3+k] + t[3-k], s), k = 1..3 (SymmColumnFilter), then cvRound (saturate_cast<uchar>)
+            const float *t = hb + (ixs[e] + dxo) * KP_HSTRIDE + (iys[e] + dyo);
+            float sacc = g3 * t[3];
+            sacc = __builtin_fmaf(g4, t[4] + t[2], sacc);
+            sacc = __builtin_fmaf(g5, t[5] + t[1], sacc);
+            sacc = __builtin_fmaf(g6, t[6] + t[0], sacc);
+            t01[e] = __builtin_rintf(sacc);                           // 0 <= value <= 255 (convex combination of bytes): no saturation to apply
         }
         nib |= (unsigned)(t01[0] < t01[1]) << bit;
     }
@@ -1071,8 +1052,8 @@ void rpe_launch_angle(rpe_handle *h, int n_img)
 
 // ------------------------------------------------------------------- blur
 // GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) as ORB runs it (in place on a pyramid sub-matrix => cv2's
-// sepFilter2D route): separable integer kernel cvRound(256 g_i) = [18,34,49,55,49,34,18] (sum 257);
-// result saturate_u8((sum + 2^15) >> 16).
+// sepFilter2D f32 route, see orient_describe_kernel): row pass s = g0 p[x-3], s = fma(g_k, p[x-3+k], s); column pass
+// s = g3 c, s = fma(g_{3+k}, r[y+k] + r[y-k], s); result cvRound(s).  Whole levels, for rpe_orb_debug_fetch only.
 __device__ __forceinline__ int refl101(int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * n - 2 - p : p; }
 
 __global__ __launch_bounds__(256) void blur_kernel(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ dst,
@@ -1081,7 +1062,7 @@ __global__ __launch_bounds__(256) void blur_kernel(const uint8_t *__restrict__ p
     // 64x64 tile; input 70 rows x 72 bytes (x0-4 .. x0+67) loaded as aligned dwords; rows
     // are reflected at load time, the <=3 reflected columns per side are patched in LDS.
     __shared__ unsigned s_in[(TH + 6) * 18];
-    __shared__ uint2 s_h[(TH + 6) * 16];          // horizontal pass: 4 x u16 per entry
+    __shared__ float4 s_h[(TH + 6) * 16];          // horizontal pass: 4 x f32 per entry
     const int tid = threadIdx.x;
     const RpeTile t = tiles[blockIdx.x];
     const RpeLevel &L = lay.lv[t.level];
@@ -1109,33 +1090,42 @@ __global__ __launch_bounds__(256) void blur_kernel(const uint8_t *__restrict__ p
         }
     }
     __syncthreads();
+    const float g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];
     for (int i = tid; i < (TH + 6) * 16; i += 256) {
         int r = i >> 4, c = i & 15;
         unsigned a = s_in[r * 18 + c], b = s_in[r * 18 + c + 1], d = s_in[r * 18 + c + 2];
-        unsigned p[12];
+        float p[12];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { p[k] = (a >> (8 * k)) & 255; p[4 + k] = (b >> (8 * k)) & 255; p[8 + k] = (d >> (8 * k)) & 255; }
-        unsigned o[4];
+        for (int k = 0; k < 4; ++k) { p[k] = (float)((a >> (8 * k)) & 255u); p[4 + k] = (float)((b >> (8 * k)) & 255u); p[8 + k] = (float)((d >> (8 * k)) & 255u); }
+        float o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            o[j] = 18u * p[j + 1] + 34u * p[j + 2] + 49u * p[j + 3] + 55u * p[j + 4] + 49u * p[j + 5] + 34u * p[j + 6] + 18u * p[j + 7];
-        s_h[i] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+        for (int j = 0; j < 4; ++j) {
+            float sacc = g0 * p[j + 1];
+            sacc = __builtin_fmaf(g1, p[j + 2], sacc); sacc = __builtin_fmaf(g2, p[j + 3], sacc); sacc = __builtin_fmaf(g3, p[j + 4], sacc);
+            sacc = __builtin_fmaf(g2, p[j + 5], sacc); sacc = __builtin_fmaf(g1, p[j + 6], sacc); sacc = __builtin_fmaf(g0, p[j + 7], sacc);
+            o[j] = sacc;
+        }
+        s_h[i] = make_float4(o[0], o[1], o[2], o[3]);
     }
     __syncthreads();
     const int tx = tid & 15, tyb = tid >> 4;
-    const unsigned kk[7] = {18u, 34u, 49u, 55u, 49u, 34u, 18u};
 #pragma unroll
     for (int rr = 0; rr < TH / 16; ++rr) {
         const int ty = tyb + 16 * rr;
-        unsigned acc[4] = {0, 0, 0, 0};
+        float4 r[7];
 #pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            uint2 v = s_h[(ty + r) * 16 + tx];
-            acc[0] += kk[r] * (v.x & 0xFFFF); acc[1] += kk[r] * (v.x >> 16);
-            acc[2] += kk[r] * (v.y & 0xFFFF); acc[3] += kk[r] * (v.y >> 16);
-        }
-        unsigned out = min((acc[0] + 32768u) >> 16, 255u) | (min((acc[1] + 32768u) >> 16, 255u) << 8) |
-                       (min((acc[2] + 32768u) >> 16, 255u) << 16) | (min((acc[3] + 32768u) >> 16, 255u) << 24);
+        for (int k = 0; k < 7; ++k) r[k] = s_h[(ty + k) * 16 + tx];
+        auto col = [&](float c, float a1, float b1, float a2, float b2, float a3, float b3) -> unsigned {
+            float sacc = g3 * c;
+            sacc = __builtin_fmaf(g2, a1 + b1, sacc);
+            sacc = __builtin_fmaf(g1, a2 + b2, sacc);
+            sacc = __builtin_fmaf(g0, a3 + b3, sacc);
+            return (unsigned)min(max(__float2int_rn(sacc), 0), 255);
+        };
+        unsigned out = col(r[3].x, r[4].x, r[2].x, r[5].x, r[1].x, r[6].x, r[0].x) |
+                       (col(r[3].y, r[4].y, r[2].y, r[5].y, r[1].y, r[6].y, r[0].y) << 8) |
+                       (col(r[3].z, r[4].z, r[2].z, r[5].z, r[1].z, r[6].z, r[0].z) << 16) |
+                       (col(r[3].w, r[4].w, r[2].w, r[5].w, r[1].w, r[6].w, r[0].w) << 24);
         int px = x0 + 4 * tx, py = y0 + ty;
         if (py < hgt && px < pitch) *(unsigned *)(dst + ibase + (long long)py * pitch + px) = out;
     }

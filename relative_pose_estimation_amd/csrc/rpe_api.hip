@@ -43,6 +43,7 @@ extern "C" void rpe_default_config(rpe_config *c)
     c->ransac_threshold = 1.0;             // pose_estimator.py:526
     c->match_mode = RPE_MATCH_CROSSCHECK;  // pose_estimator.py:131 crossCheck=True
     c->match_ratio = 0.75;
+    c->stl_runtime = RPE_STL_LIBSTDCXX;    // the reference's Linux cv2 wheels (Dockerfile: python:3.9-slim)
 }
 
 extern "C" int rpe_device_count(void)
@@ -86,12 +87,20 @@ static void build_layout(rpe_handle *h)
         nd *= factor;
     }
     L.lv[RPE_NLEVELS - 1].quota = nf - sum > 0 ? nf - sum : 0;
+    int corner = 0;
     for (int l = 0; l < RPE_NLEVELS; ++l) {
-        L.lv[l].ccap = 4 * L.lv[l].quota + 256;
+        // raster corner list: clamp(w h / 64, 1024, 8192) entries (the oracle mirrors this rule: orc_orb_corner_cap)
+        const long long c64 = (long long)L.lv[l].w * L.lv[l].h / 64;
+        L.lv[l].ccap = (int)(c64 < 1024 ? 1024 : c64 > 8192 ? 8192 : c64);
+        L.lv[l].corner_off = corner;
+        corner += L.lv[l].ccap;
+        L.lv[l].kcap2 = 4 * L.lv[l].quota + 256;
         L.lv[l].cand_off = cand;
-        cand += L.lv[l].ccap;
+        cand += L.lv[l].kcap2;
     }
+    L.corner_total = corner;
     L.cand_total = cand;
+    L.stl = h->cfg.stl_runtime;
     L.kcap = nf + 64;
     L.fast_thr = h->cfg.fast_threshold;
 }
@@ -290,6 +299,7 @@ static int alloc_workspace(rpe_handle *h)
     DM(h, h->d_hist, NI * RPE_NLEVELS * 256);
     DM(h, h->d_cand_xy, NI * L.cand_total); DM(h, h->d_cand_resp, NI * L.cand_total);
     DM(h, h->d_cand_count, NI * RPE_NLEVELS);
+    DM(h, h->d_corner, NIo * L.corner_total); DM(h, h->d_corner_count, NI * RPE_NLEVELS); DM(h, h->d_kp_lvl_count, NI * RPE_NLEVELS);
     DM(h, h->d_kp_xy, NI * L.kcap); DM(h, h->d_kp_resp, NI * L.kcap); DM(h, h->d_kp_angle, NI * L.kcap);
     DM(h, h->d_kp_pt, NI * L.kcap); DM(h, h->d_kp_cs, NI * L.kcap); DM(h, h->d_kp_count, NI);
     DM(h, h->d_ovf, NI);
@@ -305,7 +315,7 @@ static int alloc_workspace(rpe_handle *h)
     h->d_inliers = (int *)(h->d_t + (size_t)B * 3); h->d_status = h->d_inliers + B; h->d_m_n = h->d_status + B;
     HIPCHK(h, hipHostMalloc((void **)&h->h_resblk, (size_t)B * RPE_RESULT_BYTES));
     DM(h, h->d_pts1, B * mm); DM(h, h->d_pts2, B * mm);
-    if (h->cfg.norm_type == RPE_NORM_L2) DM(h, h->d_m_best, B * L.kcap);
+    if (h->cfg.norm_type == RPE_NORM_L2) { DM(h, h->d_m_best, B * L.kcap); DM(h, h->d_m_best2, B * L.kcap); }
     DM(h, h->d_n1, B * mm); DM(h, h->d_n2, B * mm);
     DM(h, h->d_rstate, B); DM(h, h->d_found, B);
     DM(h, h->d_models, B * RPE_RANSAC_MAXCHUNK * RPE_MAX_MODELS * 9);
@@ -331,6 +341,11 @@ extern "C" int rpe_create(const rpe_config *cfg, rpe_handle **out)
         g_create_err = "NORM_HAMMING needs 8-bit descriptors: SIFT descriptors are float (cv2 raises in match())"; return RPE_ERR_INVALID;
     }
     if (cfg->match_mode != RPE_MATCH_CROSSCHECK && cfg->match_mode != RPE_MATCH_RATIO) { g_create_err = "unknown match mode"; return RPE_ERR_INVALID; }
+    if (cfg->norm_type == RPE_NORM_L2 && cfg->nfeatures > 4032) {
+        // the L2 matcher sorts next_pow2(nfeatures + 64) 64-bit keys in LDS: 4096 keys = 32 KB
+        g_create_err = "NORM_L2: nfeatures must be <= 4032"; return RPE_ERR_INVALID;
+    }
+    if (cfg->stl_runtime != RPE_STL_LIBSTDCXX && cfg->stl_runtime != RPE_STL_MSVC) { g_create_err = "unknown stl_runtime"; return RPE_ERR_INVALID; }
     if (cfg->match_mode == RPE_MATCH_RATIO && !(cfg->match_ratio > 0. && cfg->match_ratio <= 1.)) { g_create_err = "match_ratio must be in (0, 1]"; return RPE_ERR_INVALID; }
     if (is_sift && (cfg->nfeatures > 4032 || cfg->nfeatures < 1 || cfg->width > 4000 || cfg->height > 4000)) {
         g_create_err = "SIFT: nfeatures (keypoint cap) must be <= 4032 and the image <= 4000 px"; return RPE_ERR_INVALID;
@@ -375,7 +390,7 @@ extern "C" void rpe_destroy(rpe_handle *h)
                     h->d_hist, h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_angle,
                     h->d_kp_pt, h->d_kp_cs, h->d_kp_count, h->d_desc, h->d_m_q, h->d_m_t, h->d_m_d, h->d_resblk, h->d_pts1, h->d_pts2,
                     h->d_subsets, h->d_nit_denom, h->d_nit_round, h->d_rstate, h->d_n1, h->d_n2, h->d_found, h->d_models, h->d_hyp, h->d_counts,
-                    h->d_nmodels, h->d_mask, h->d_E, h->d_K, h->d_m_best, h->d_ovf};
+                    h->d_nmodels, h->d_mask, h->d_E, h->d_K, h->d_m_best, h->d_m_best2, h->d_ovf, h->d_corner, h->d_corner_count, h->d_kp_lvl_count};
     for (void *p : ptrs) if (p) hipFree(p);
     if (h->h_resblk) hipHostFree(h->h_resblk);
     for (void *p : h->user_allocs) hipFree(p);
@@ -643,7 +658,12 @@ extern "C" int rpe_fetch_results(rpe_handle *h, int B, double *R, double *t, int
 extern "C" int rpe_fetch_overflow(rpe_handle *h, int n_pairs, uint32_t *flags)
 {
     if (!h || !flags || n_pairs < 1 || n_pairs > h->cfg.max_batch) return RPE_ERR_INVALID;
-    if (h->last_chunked) { h->err = "the last host batch ran in chunks: capacity flags are kept for single-launch batches only"; return RPE_ERR_INVALID; }
+    if (h->last_chunked) {
+        // a chunked host batch reuses the per-image flag words chunk after chunk: they were collected per pair as the chunks finished
+        if ((size_t)n_pairs > h->ovf_pairs.size()) { h->err = "rpe_fetch_overflow: more pairs than the last batch had"; return RPE_ERR_INVALID; }
+        memcpy(flags, h->ovf_pairs.data(), sizeof(uint32_t) * (size_t)n_pairs);
+        return RPE_OK;
+    }
     if (n_pairs > h->last_pairs) { h->err = "rpe_fetch_overflow: more pairs than the last batch had"; return RPE_ERR_INVALID; }
     const int nimg = h->last_img2_base + n_pairs;
     std::vector<unsigned> ov((size_t)nimg);
@@ -695,6 +715,8 @@ extern "C" int rpe_estimate_batch(rpe_handle *h, const uint8_t *h_imgs1, const u
     // kernels of chunk c are queued BEFORE the upload of chunk c+1 is issued, results of c are fetched after it
     int rc = upload(0);
     if (rc) return rc;
+    h->ovf_pairs.assign((size_t)B, 0u);
+    std::vector<unsigned> ov;
     for (int c = 0; c < nchunks; ++c) {
         const int off = c * per, n = B - off < per ? B - off : per;
         if (n <= 0) break;
@@ -704,6 +726,11 @@ extern "C" int rpe_estimate_batch(rpe_handle *h, const uint8_t *h_imgs1, const u
         rc = rpe_fetch_results(h, n, R ? R + 9 * (size_t)off : nullptr, t ? t + 3 * (size_t)off : nullptr,
                                inliers ? inliers + off : nullptr, n_matches ? n_matches + off : nullptr, status ? status + off : nullptr);
         if (rc) return rc;
+        // the chunk's capacity flags (image slots p and n + p of this launch), before the next chunk overwrites them
+        ov.resize((size_t)h->last_img2_base + n);
+        HIPCHK(h, hipMemcpyAsync(ov.data(), h->d_ovf, sizeof(unsigned) * ov.size(), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (int p2 = 0; p2 < n; ++p2) h->ovf_pairs[(size_t)off + p2] = ov[p2] | ov[(size_t)h->last_img2_base + p2];
     }
     h->last_chunked = true;
     return RPE_OK;

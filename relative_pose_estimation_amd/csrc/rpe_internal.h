@@ -28,7 +28,9 @@
 struct RpeLevel {
     int w, h, pitch;
     int quota;        // features kept on this level (orb.cpp nfeaturesPerLevel)
-    int ccap;         // candidate capacity 4*quota+256
+    int ccap;         // capacity of the level's raster corner list: clamp(w h / 64, 1024, 8192) (cv2 has none: flagged when hit)
+    int corner_off;   // offset of this level inside the per-image corner array
+    int kcap2;        // capacity of the candidate list after retainBest(2 quota) (FAST-score ties extend it): 4 quota + 256
     int cand_off;     // offset of this level inside per-image candidate arrays
     float scale;      // (float)pow(1.1f, l)
     long long off;    // byte offset inside the per-image pyramid buffer
@@ -40,7 +42,9 @@ struct RpeLevel {
 struct RpeDeviceLayout {       // passed by value to kernels
     RpeLevel lv[RPE_NLEVELS];
     long long stride;          // bytes per image in pyramid-shaped buffers
-    int cand_total;            // candidates capacity per image (sum ccap)
+    int corner_total;          // raster corner capacity per image (sum ccap)
+    int cand_total;            // candidates capacity per image (sum kcap2)
+    int stl;                   // C++ runtime whose nth_element orders the keypoints (rb::RT_LIBSTDCXX / rb::RT_MSVC, cfg.stl_runtime)
     int kcap;                  // keypoints capacity per image
     int fast_thr;
     // level 0 read IN PLACE from the caller's image batches when its pitch equals the image width (width % 16 == 0):
@@ -127,6 +131,7 @@ struct rpe_handle {
     hipStream_t copy_stream = nullptr;          // uploads of a chunked host batch (rpe_estimate_batch), created on first use
     hipEvent_t ev_up[8] = {};                   // 'chunk c is resident' events
     bool last_chunked = false;                  // the last host batch ran in chunks: per-pair debug arrays hold its last chunk only
+    std::vector<uint32_t> ovf_pairs;            // capacity flags of a chunked host batch, per pair (OR of the pair's two images), kept across its chunks
     RpeDeviceLayout lay{};
     int n_img_cap = 0;              // 2*max_batch
     // tile tables
@@ -143,6 +148,9 @@ struct rpe_handle {
     uint8_t *d_stage1 = nullptr, *d_stage2 = nullptr; // staging for host-image API
     // detection
     unsigned *d_hist = nullptr;       // [img][level][256]
+    unsigned *d_corner = nullptr;     // [img][corner_total] raster-ordered FAST corners of a level: score << 24 | y << 12 | x
+    int *d_corner_count = nullptr;    // [img][level]
+    int *d_kp_lvl_count = nullptr;    // [img][level] keypoints kept per level (head of the level's candidate run)
     unsigned *d_cand_xy = nullptr;    // [img][cand_total]  y<<16|x
     float *d_cand_resp = nullptr;     // [img][cand_total]
     int *d_cand_count = nullptr;      // [img][level]
@@ -158,6 +166,7 @@ struct rpe_handle {
     // matching
     int *d_m_q = nullptr, *d_m_t = nullptr, *d_m_d = nullptr, *d_m_n = nullptr;
     unsigned long long *d_m_best = nullptr;   // L2 matcher: [pair][kcap] packed (f32 dist bits << 18 | trainIdx) of the best elector
+    unsigned long long *d_m_best2 = nullptr;  // L2 matcher: [pair][kcap] the same key of the query's own nearest train (second crossCheck pass)
     float2 *d_pts1 = nullptr, *d_pts2 = nullptr;   // [pair][max_matches]
     // RANSAC
     unsigned short *d_subsets = nullptr;  // [M 0..max_matches][iters][5]

@@ -7,9 +7,10 @@ estimate_with_debug(...) -> dict with the reference's keys (:571-688, dict
 :529-530).  Added: estimate_batch() for many pairs per call.
 
 Scope: the feature -> match -> essential -> pose path on the GPU: ORB or SIFT features, Hamming or L2 matcher
-(every combination cv2 can run: ORB + Hamming, ORB + L2, SIFT + L2; SIFT + Hamming fails in cv2's match() and is
-rejected here at construction).  Added, opt-in and NOT in the reference: `ratio` = Lowe ratio test instead of
-crossCheck.  VP refinement
+(every combination cv2 can run: ORB + Hamming, ORB + L2, SIFT + L2; SIFT + Hamming constructs, as in the reference,
+and fails at the first estimate with cv2's batchDistance message, where the reference's match() fails).  Added, opt-in
+and NOT in the reference: `ratio` = Lowe ratio test instead of crossCheck; `keypoint_order` = which cv2 build's
+keypoint order to reproduce ("libstdc++": the Linux wheels, default; "msvc": the Windows wheels).  VP refinement
 (:160-481, :536-567) is the reference's CPU post-step on R; it is applied exactly where the
 reference applies it -- `use_vp_refinement` set and `R_prev` given -- by vp_refinement.py on top of the
 library's LSD restatement (host code, as in the reference).
@@ -36,7 +37,8 @@ class PoseEstimator:
                  vp_cost_improve_eps=1e-3,
                  device=0,
                  max_batch=1,
-                 ratio=None):
+                 ratio=None,
+                 keypoint_order="libstdc++"):
         self.K = np.asarray(camera_matrix, dtype=np.float64)
         self.feature_method = feature_method
         self.norm_type = norm_type
@@ -68,13 +70,23 @@ class PoseEstimator:
             self._norm = _capi.NORM_L2
         else:
             raise ValueError(f"Unknown norm type: {norm}")
-        if (self._feature, self._norm) == (_capi.FEATURE_SIFT, _capi.NORM_HAMMING):
-            # cv2 builds this matcher (pose_estimator.py:131) but its match() raises on float descriptors
-            # (batchDistance: NORM_HAMMING needs CV_8U); a GPU handle is not created for a path that cannot run
-            raise ValueError("NORM_HAMMING cannot match SIFT's float descriptors (cv2 raises in BFMatcher.match)")
+        # cv2 builds the SIFT + NORM_HAMMING matcher too (pose_estimator.py:131) and only its match() (:144) raises, on the
+        # float descriptors: so does this class -- construction succeeds, the first estimate raises (_check_runnable)
+        self._unrunnable = (self._feature, self._norm) == (_capi.FEATURE_SIFT, _capi.NORM_HAMMING)
+        if keypoint_order not in ("libstdc++", "msvc"):
+            raise ValueError(f"Unknown keypoint order: {keypoint_order}")
+        self.keypoint_order = keypoint_order
         self._engines = {}
 
+    def _check_runnable(self):
+        if self._unrunnable:
+            # cv2.error is not a RuntimeError; the text is batchDistance's (core/batch_distance.cpp): type CV_32F = 5,
+            # dtype CV_32S = 4, NORM_HAMMING = 6
+            raise RuntimeError("OpenCV: (-210:Unsupported format or combination of formats) The combination of type=5, dtype=4 "
+                               "and normType=6 is not supported in function 'batchDistance'")
+
     def _engine(self, height, width, batch):
+        self._check_runnable()
         key = (height, width)
         eng = self._engines.get(key)
         if eng is None or eng.max_batch < batch:
@@ -90,7 +102,8 @@ class PoseEstimator:
             eng = _capi.Engine(width, height, max_batch=max(batch, self.max_batch), nfeatures=nf,
                                max_matches=mm, device=self.device, feature_method=self._feature, norm_type=self._norm,
                                match_mode=_capi.MATCH_RATIO if self.ratio is not None else _capi.MATCH_CROSSCHECK,
-                               match_ratio=float(self.ratio) if self.ratio is not None else 0.75)
+                               match_ratio=float(self.ratio) if self.ratio is not None else 0.75,
+                               stl_runtime=_capi.STL_MSVC if self.keypoint_order == "msvc" else _capi.STL_LIBSTDCXX)
             self._engines[key] = eng
         return eng
 

@@ -6,7 +6,8 @@ is one all-gather of fixed-size 128-byte pose records at the end of a step:
 
   * `PoseComm` -- the product path: `rpe_gather_poses` in librpe_amd.so, an ncclAllGather over RCCL / xGMI on
     the engine's HIP stream, records packed on the device.  No torch: ranks bootstrap through the RCCL unique
-    id that rank 0 writes to a file (one node, so a local path is visible to every rank).
+    id that rank 0 publishes in a per-user rendezvous directory (one node, so a local path is visible to every
+    rank), and they AGREE on the outcome of every set-up phase, so a failure on one rank is a failure on all.
   * `gather_pose_records` -- the same exchange through an already initialised torch.distributed group; used
     by the CPU tests (backend "gloo", world size 2) and by `bench.py --dist-backend gloo` rehearsals.
 
@@ -57,62 +58,134 @@ def pack_records(R, t, inliers, status, n_matches, first_pair=0):
 
 
 # ----------------------------------------------------------------------------- native RCCL path (no torch)
-def _id_path(tag=None):
-    # MASTER_PORT + run id + the launcher's pid (every rank is a child of the same torch.distributed.run agent): a file
-    # left behind by a crashed earlier launch on the same port can never be mistaken for this launch's id
-    tag = "{}_{}_{}_{}".format(os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid(), tag or "")
-    return os.path.join(os.environ.get("RPE_COMM_DIR", "/tmp"), f"rpe_comm_{tag}.id")
+class CommUnavailable(RuntimeError):
+    """The native pose gather cannot be set up on this node.  Raised by EVERY rank of the job (the outcome of each
+    set-up phase is agreed through the rendezvous directory), so all ranks take the same way out."""
 
 
-def exchange_unique_id(lib, rank, world, tag=None, timeout=300.0):
-    """Rank 0 asks RCCL for a unique id and publishes it atomically (write + rename); the others poll for the file.
-    The launcher contract (python -m torch.distributed.run, one node) provides RANK / WORLD_SIZE / MASTER_PORT in the
-    environment; nothing else of torch is used."""
-    path = _id_path(tag)
-    if rank == 0:
+class Rendezvous:
+    """File rendezvous of the ranks of ONE node (the sharded path is one process per GPU of one node, so a local
+    directory is visible to every rank).  One directory per job inside a per-user 0700 directory; every file is
+    created exclusively with mode 0600 and published by rename, so a reader sees a whole file or none.
+
+    The job tag must be the same on all ranks and different from any other job of this user on this node:
+      * RPE_COMM_TAG, if set (any launcher: mpirun, srun, a wrapper shell per rank);
+      * else MASTER_ADDR, MASTER_PORT and TORCHELASTIC_RUN_ID plus -- only under `python -m torch.distributed.run`,
+        which sets TORCHELASTIC_RUN_ID and is the parent of every rank -- that launcher's pid, which keeps files
+        left behind by a crashed earlier launch on the same port from being mistaken for this launch's."""
+
+    def __init__(self, rank, world, tag=None, timeout=300.0, root=None):
+        self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
+        env = os.environ
+        job = env.get("RPE_COMM_TAG")
+        if not job:
+            job = "{}_{}_{}".format(env.get("MASTER_ADDR", "127.0.0.1"), env.get("MASTER_PORT", "0"), env.get("TORCHELASTIC_RUN_ID", "none"))
+            if "TORCHELASTIC_RUN_ID" in env:
+                job += f"_p{os.getppid()}"
+        job = "".join(ch if ch.isalnum() or ch in "._-" else "_" for ch in f"{job}_{tag or ''}")
+        root = root or env.get("RPE_COMM_DIR") or os.path.join("/tmp", f"rpe_comm_{os.getuid()}")
+        os.makedirs(root, mode=0o700, exist_ok=True)
+        st = os.stat(root)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise CommUnavailable(f"rendezvous directory {root} is not private to this user")
+        self.dir = os.path.join(root, job)
+        os.makedirs(self.dir, mode=0o700, exist_ok=True)
+
+    def publish(self, name, payload=b""):
+        final = os.path.join(self.dir, name)
+        tmp = f"{final}.tmp{os.getpid()}"
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        try:
+            os.write(fd, payload)
+        finally:
+            os.close(fd)
+        os.replace(tmp, final)
+
+    def wait(self, name):
+        path = os.path.join(self.dir, name)
+        t0 = time.time()
+        while True:
+            try:
+                with open(path, "rb") as fh:
+                    return fh.read()
+            except FileNotFoundError:
+                pass
+            if time.time() - t0 > self.timeout:
+                raise CommUnavailable(f"rank {self.rank}: nothing at {path} after {self.timeout:g} s")
+            time.sleep(0.02)
+
+    def agree(self, phase, ok, message=""):
+        """Every rank reports the outcome of `phase`; returns normally on ALL ranks if all succeeded, raises
+        CommUnavailable on ALL ranks otherwise (a rank that died is a timeout, i.e. also a raise everywhere)."""
+        self.publish(f"{phase}.{self.rank}", (b"ok" if ok else b"fail:" + str(message).encode()))
+        bad = []
+        for r in range(self.world):
+            data = self.wait(f"{phase}.{r}")
+            if data != b"ok":
+                bad.append(f"rank {r}: {data[5:].decode(errors='replace') or 'failed'}")
+        if bad:
+            raise CommUnavailable(f"{phase}: " + "; ".join(bad))
+
+    def cleanup(self):
+        """rank 0, after the last agreement: the job's files are of no further use"""
+        try:
+            for f in os.listdir(self.dir):
+                os.remove(os.path.join(self.dir, f))
+            os.rmdir(self.dir)
+        except OSError:
+            pass
+
+
+def exchange_unique_id(lib, rdv):
+    """Rank 0 asks RCCL for a unique id and publishes it -- or publishes WHY it could not, so that the other ranks stop
+    waiting; the others read it.  Raises CommUnavailable on every rank when rank 0 failed."""
+    if rdv.rank == 0:
         buf = (C.c_uint8 * 128)()
         rc = lib.rpe_comm_unique_id(buf)
         if rc != 0:
-            raise RuntimeError(f"rpe_comm_unique_id failed ({rc}): {lib.rpe_comm_last_error().decode()}")
-        tmp = path + f".tmp{os.getpid()}"
-        with open(tmp, "wb") as fh:
-            fh.write(bytes(buf))
-        os.replace(tmp, path)
+            msg = f"rpe_comm_unique_id failed ({rc}): {lib.rpe_comm_last_error().decode()}"
+            rdv.publish("id", b"FAIL" + msg.encode())
+            raise CommUnavailable(msg)
+        rdv.publish("id", bytes(buf))
         return bytes(buf)
-    t0 = time.time()
-    while True:
-        try:
-            with open(path, "rb") as fh:
-                data = fh.read()
-            if len(data) == 128:
-                return data
-        except FileNotFoundError:
-            pass
-        if time.time() - t0 > timeout:
-            raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout} s")
-        time.sleep(0.05)
+    data = rdv.wait("id")
+    if data[:4] == b"FAIL" or len(data) != 128:
+        raise CommUnavailable("rank 0: " + (data[4:].decode(errors="replace") if data[:4] == b"FAIL" else "malformed unique id"))
+    return data
 
 
 class PoseComm:
-    """RCCL communicator bound to one Engine (one GPU): gather of pose records, barrier, max-reduce of a scalar."""
+    """RCCL communicator bound to one Engine (one GPU): gather of pose records, barrier, max-reduce of a scalar.
+    Set-up is collective in its OUTCOME: the ranks agree after the local phase (librccl loaded, device buffers allocated)
+    and again after ncclCommInitRank; if any rank failed a phase every rank raises CommUnavailable and nobody is left
+    waiting inside a collective."""
 
-    def __init__(self, engine, rank, world, tag=None):
+    def __init__(self, engine, rank, world, tag=None, timeout=300.0):
         self.eng, self.rank, self.world = engine, rank, world
+        self.c = None
         lib = engine.lib
-        self._path = _id_path(tag)
-        uid = exchange_unique_id(lib, rank, world, tag)
-        idbuf = (C.c_uint8 * 128).from_buffer_copy(uid)
-        c = C.c_void_p()
-        rc = lib.rpe_comm_create(engine.h, rank, world, idbuf, C.byref(c))
-        if rc != 0:
-            raise RuntimeError(f"rpe_comm_create failed ({rc}): {lib.rpe_comm_last_error().decode()}")
-        self.c = c
-        self.barrier()                                   # every rank has read the id: rank 0 may remove the file
-        if rank == 0:
-            try:
-                os.remove(self._path)
-            except OSError:
-                pass
+        rdv = Rendezvous(rank, world, tag, timeout)
+        try:
+            uid = exchange_unique_id(lib, rdv)
+            c = C.c_void_p()
+            rc = lib.rpe_comm_prepare(engine.h, rank, world, C.byref(c))          # local: dlopen librccl, hipMalloc
+            if rc == 0:
+                self.c = c
+            rdv.agree("prepare", rc == 0, "" if rc == 0 else f"rpe_comm_prepare ({rc}): {lib.rpe_comm_last_error().decode()}")
+            idbuf = (C.c_uint8 * 128).from_buffer_copy(uid)
+            rc = lib.rpe_comm_connect(self.c, idbuf)                                # collective: ncclCommInitRank
+            rdv.agree("connect", rc == 0, "" if rc == 0 else f"rpe_comm_connect ({rc}): {lib.rpe_comm_last_error().decode()}")
+            self.barrier()
+            rdv.agree("barrier", True)
+            self.barrier()                                   # every rank is past its last read of the rendezvous files
+            if rank == 0:
+                rdv.cleanup()
+        except BaseException:
+            self.close()
+            if rank == 0:                                    # the others poll every 20 ms: give them time to read the verdict
+                time.sleep(2.0)
+                rdv.cleanup()
+            raise
 
     def _chk(self, rc, what):
         if rc != 0:

@@ -1,0 +1,51 @@
+// Host harness for relative_pose_estimation_amd/csrc/retain_best_emul.h (tests/test_retain_best_cpu.py):
+// the restated libstdc++ selection against the REAL std::nth_element + std::partition of this container.
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+#include "../../relative_pose_estimation_amd/csrc/retain_best_emul.h"
+
+namespace {
+struct Kp { float response; int32_t id; };
+struct GT { bool operator()(const Kp &a, const Kp &b) const { return a.response > b.response; } };
+struct GE { bool operator()(const Kp &a, const Kp &b) const { return a.response >= b.response; } };
+}
+
+// runs both on (resp[i], i); out_real / out_emul receive the ids in the resulting order; returns the two sizes packed
+extern "C" int rb_run(const float *resp, int n, int n_points, int runtime, int32_t *out_real, int32_t *out_emul, int *n_real, int *n_emul)
+{
+    std::vector<Kp> a((size_t)n), b((size_t)n);
+    for (int i = 0; i < n; ++i) { a[(size_t)i].response = resp[i]; a[(size_t)i].id = i; b[(size_t)i] = a[(size_t)i]; }
+    // cv::KeyPointsFilter::retainBest on the real library (libstdc++ here)
+    if (n_points >= 0 && a.size() > (size_t)n_points) {
+        if (n_points == 0) a.clear();
+        else {
+            std::nth_element(a.begin(), a.begin() + n_points - 1, a.end(), GT());
+            const float amb = a[(size_t)n_points - 1].response;
+            std::vector<Kp>::iterator e = std::partition(a.begin() + n_points, a.end(), [amb](const Kp &k) { return k.response >= amb; });
+            a.resize((size_t)(e - a.begin()));
+        }
+    }
+    const int m = rb::retain_best(b.data(), n, n_points, runtime, GT(), GE());
+    *n_real = (int)a.size(); *n_emul = m;
+    for (size_t i = 0; i < a.size(); ++i) out_real[i] = a[i].id;
+    for (int i = 0; i < m; ++i) out_emul[i] = b[(size_t)i].id;
+    return 0;
+}
+
+// the heap_select branch of introselect (depth limit 0 from the start): result must still be a valid selection
+extern "C" int rb_heap_path_valid(const float *resp, int n, int nth)
+{
+    std::vector<Kp> b((size_t)n);
+    for (int i = 0; i < n; ++i) { b[(size_t)i].response = resp[i]; b[(size_t)i].id = i; }
+    rb::gnu_nth_element(b.data(), n, nth, GT(), 0);
+    std::vector<float> s(resp, resp + n);
+    std::sort(s.begin(), s.end(), [](float x, float y) { return x > y; });
+    if (b[(size_t)nth].response != s[(size_t)nth]) return 0;
+    for (int i = 0; i < nth; ++i) if (b[(size_t)i].response < b[(size_t)nth].response) return 0;
+    for (int i = nth + 1; i < n; ++i) if (b[(size_t)i].response > b[(size_t)nth].response) return 0;
+    std::vector<int> seen((size_t)n, 0);
+    for (int i = 0; i < n; ++i) seen[(size_t)b[(size_t)i].id]++;
+    for (int i = 0; i < n; ++i) if (seen[(size_t)i] != 1) return 0;
+    return 1;
+}

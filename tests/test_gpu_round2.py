@@ -104,8 +104,8 @@ def test_statuses_end_to_end(capi, oracle, K_vga):
     ok1, ok2, _, _ = synthetic.make_batch(1, K_vga, cfg=2)
     flat = np.full((480, 640), 128, np.uint8)
     cases = [
-        (_blobs(46, 1, 14, 40), _blobs(1046, 1, 14, 40), capi.PAIR_INSUFFICIENT_MATCHES),
-        (_blobs(5, 1, 4, 12), _blobs(5005, 1, 4, 12), capi.PAIR_AMBIGUOUS_ESSENTIAL),
+        (_blobs(7, 1, 14, 40), _blobs(1007, 1, 14, 40), capi.PAIR_INSUFFICIENT_MATCHES),
+        (_blobs(23, 1, 14, 40), _blobs(1023, 1, 14, 40), capi.PAIR_AMBIGUOUS_ESSENTIAL),
         (flat, ok2[0], capi.PAIR_NO_DESCRIPTORS),
         (ok1[0], ok2[0], capi.PAIR_OK),
     ]
@@ -198,8 +198,12 @@ def test_orb_l2(capi, oracle, K_vga):
     assert nm[0] == len(qo) and np.array_equal(q[0, :nm[0]], qo) and np.array_equal(tt[0, :nm[0]], to)
     assert np.array_equal(d[0, :nm[0]].view(np.uint32), do.view(np.uint32))
     e.close()
-    with pytest.raises(ValueError, match="NORM_HAMMING cannot match SIFT"):
-        PoseEstimator(K_vga, feature_method="SIFT", norm_type="Hamming")
+    # SIFT + Hamming: constructs like the reference (pose_estimator.py:115-131) and fails where the reference's match() fails (:144)
+    pe = PoseEstimator(K_vga, feature_method="SIFT", norm_type="Hamming")
+    with pytest.raises(RuntimeError, match="normType=6 is not supported in function 'batchDistance'"):
+        pe.estimate(i1[0], i2[0])
+    with pytest.raises(RuntimeError, match="batchDistance"):
+        pe.estimate_batch(i1, i2)
 
 
 # ------------------------------------------------------------------ Lowe ratio (opt-in extension; the reference has none)

@@ -1,0 +1,118 @@
+"""GPU parity tests added in round 3 (through the C-ABI, against the CPU oracle and against the reference's own
+committed answers): every one of the 147 result rows of the reference on the GPU; the 4096-pair shard of BASELINE
+configs[3] on one GPU; capacity flags after a chunked host batch."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import reference_rows as rr
+
+pytestmark = pytest.mark.gpu
+NTHREADS = max(1, min(16, os.cpu_count() or 1))
+RUNTIME = {"sim": "msvc", "salah": "libstdc++", "phone": "libstdc++"}     # tests/test_reference_rows_cpu.py
+FLOOR = {"sim": 45, "salah": 69, "phone": 8}
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+    yield o
+    o.set_stl("libstdc++")
+
+
+@pytest.mark.parametrize("name", rr.NAMES)
+def test_every_reference_row_on_the_gpu(oracle, name):
+    """All rows of one reference result file (simulator 58 pairs at 640x480, Salah 80 at 1920x1080, phone 9 at 848x478:
+    pitch != width) with the reference's parameters (ORB 4000, top-500: pipeline.py:94-101) through estimate_batch:
+    GPU == oracle bit for bit, and the GPU's own answers against the CSV's est_* columns."""
+    from relative_pose_estimation_amd import PoseEstimator, geometry
+    ds = rr.load(name)
+    B = len(ds["frames2"])
+    pe = PoseEstimator(ds["K"], nfeatures=4000, max_matches=500, max_batch=B, keypoint_order=RUNTIME[name])
+    R, t, inl, st = pe.estimate_batch(ds["img1"], ds["img2"])
+    nm = pe._last_n_matches.copy()
+    ovf = pe.last_overflow()
+    pe.close()
+    oracle.set_stl(RUNTIME[name])
+    out = oracle.estimate_pose_batch(ds["img1"], ds["img2"], ds["K"], 4000, 500, nthreads=NTHREADS)
+    oracle.set_stl("libstdc++")
+    assert np.array_equal(st, out["status"]) and np.all(st == 0)
+    assert np.array_equal(nm, out["n_matches"]) and np.array_equal(inl, out["inliers"])
+    assert np.array_equal(ovf, out["overflow"]) and not ovf.any()
+    assert np.array_equal(R.reshape(B, 9), out["R"]) and np.array_equal(t.reshape(B, 3), out["t"])      # bit-exact (tolerance of the path: 1e-4 Frobenius)
+    diff = rr.euler_agreement(ds, R, geometry)
+    err = rr.rotation_errors(ds, R, geometry)
+    ref = ds["ref_rotation_error"]
+    counts = rr.agreement_counts(diff)
+    print(f"\n[{name}] GPU, {B} rows: est_* agree within " + ", ".join(f"{e:g} deg: {c}" for e, c in zip(rr.AGREE_EDGES, counts))
+          + f"; median rotation error GPU {np.median(err):.3f} deg, reference {np.median(ref):.3f}")
+    assert counts[0] >= FLOOR[name]
+    agree = diff < 1e-6
+    assert np.allclose(err[agree], ref[agree], atol=1e-5)
+
+
+def test_reference_stream_equals_pairs(oracle):
+    """The phone rows as ONE consecutive-frame stream through BatchProcessor (features once per frame,
+    batch_processor.py:71-109): the est_* columns it produces are the ones estimate_batch produces."""
+    from relative_pose_estimation_amd import BatchProcessor, PoseEstimator, geometry
+    ds = rr.load("phone")
+    frames = np.concatenate([ds["img1"][:1], ds["img2"]])
+    idx = [int(ds["frames1"][0])] + [int(f) for f in ds["frames2"]]
+
+    class GT:                                   # ground_truth_loader.get_pose of the committed rows
+        def get_pose(self, f):
+            i = idx.index(f)
+            g = ds["gt1"][i] if i < len(ds["gt1"]) else ds["gt2"][-1]
+            return {"roll": g[3], "pitch": g[4], "yaw": g[5]}
+    pe = PoseEstimator(ds["K"], nfeatures=4000, max_matches=500, max_batch=len(idx))
+    out = BatchProcessor(None, pe, GT(), euler_convention=ds["convention"]).process_frames(idx, frames)
+    pe.close()
+    cols = ds["columns"]
+    ref = ds["table"][:, [cols.index("est_yaw"), cols.index("est_pitch"), cols.index("est_roll")]]
+    got = np.stack([out["yaw"], out["pitch"], out["roll"]], 1)
+    d = np.abs((got - ref + 180.0) % 360.0 - 180.0).max(1)
+    assert (d < 1e-6).sum() >= FLOOR["phone"], d
+
+
+def test_shard_of_4096_pairs(oracle, K_vga):
+    """BASELINE configs[3] gives every GPU 4096 VGA pairs: that shard on ONE GPU -- the workspace for 8192 images is
+    allocated, and the results of pair i equal those of the same pair in a 64-pair batch (and the oracle's for a sample)."""
+    from relative_pose_estimation_amd import _capi, synthetic
+    i1, i2, _, _ = synthetic.make_batch(64, K_vga, cfg=31)
+    small = _capi.Engine(640, 480, max_batch=64, nfeatures=1000, max_matches=500)
+    Rs, ts, inls, nms, sts = small.estimate_batch(i1, i2, K_vga)
+    small.close()
+    big = _capi.Engine(640, 480, max_batch=4096, nfeatures=1000, max_matches=500)
+    a = np.tile(i1, (64, 1, 1)); b = np.tile(i2, (64, 1, 1))
+    d1 = big.upload(a); d2 = big.upload(b)
+    big.enqueue_batch_device(d1, d2, 4096, K_vga)
+    R, t, inl, nm, st = big.fetch_results(4096)
+    big.device_free(d1); big.device_free(d2)
+    big.close()
+    for rep in range(64):
+        s = slice(64 * rep, 64 * rep + 64)
+        assert np.array_equal(R[s], Rs) and np.array_equal(t[s], ts) and np.array_equal(inl[s], inls) and np.array_equal(st[s], sts)
+    for n in (0, 17, 63):
+        r = oracle.estimate_pose(i1[n], i2[n], K_vga, 1000, 500)
+        assert st[n] == r["status"] and nm[n] == r["n_matches"] and inl[n] == r["inliers"] and np.array_equal(R[n], r["R"])
+
+
+def test_capacity_flags_survive_a_chunked_host_batch(oracle, K_vga):
+    """rpe_estimate_batch runs 512 host pairs in four chunks (uploads behind kernels); the per-image flag words are
+    reused chunk after chunk, so the flags are collected per pair as the chunks finish: a dots image (thousands of tied
+    FAST scores) in the middle of chunk 1 still reports its truncation, nobody else does."""
+    from relative_pose_estimation_amd import _capi, synthetic
+    i1, i2, _, _ = synthetic.make_batch(8, K_vga, cfg=33)
+    a = np.tile(i1, (64, 1, 1)); b = np.tile(i2, (64, 1, 1))
+    dots = np.full((480, 640), 40, np.uint8)
+    dots[40:440:8, 40:600:8] = 220
+    a[200] = dots; b[200] = dots
+    e = _capi.Engine(640, 480, max_batch=512, nfeatures=1000, max_matches=500)
+    R, t, inl, nm, st = e.estimate_batch(a, b, K_vga)
+    ovf = e.fetch_overflow(512)
+    e.close()
+    _, _, fo = oracle.orb_detect_and_compute(dots, 1000, return_flags=True)
+    assert fo == _capi.OVF_ORB_CANDIDATES | _capi.OVF_ORB_KEYPOINTS
+    assert ovf[200] == fo and not np.delete(ovf, 200).any()
+    assert np.array_equal(R[8:16], R[:8]) and np.array_equal(R[504:512], R[:8])       # copies of a pair, whichever chunk they sit in

@@ -86,3 +86,92 @@ def test_gloo_world2_gather(tmp_path, oracle):
     ref = oracle.estimate_pose_batch(i1, i2, K, 300, 200, nthreads=1)
     assert np.array_equal(rec["R"], ref["R"]) and np.array_equal(rec["t"], ref["t"])
     assert np.array_equal(rec["inliers"], ref["inliers"]) and np.array_equal(rec["status"], ref["status"])
+
+
+# ------------------------------------------------------------------ native rendezvous (no GPU: a stub library object)
+RDV_WORKER = r"""
+import os, sys, ctypes as C
+sys.path.insert(0, os.environ["RPE_ROOT"])
+from relative_pose_estimation_amd import sharding
+
+class StubLib:                                   # the three entry points exchange_unique_id / agree use
+    def rpe_comm_unique_id(self, buf):
+        if os.environ.get("RPE_TEST_FAIL_ID"):
+            return -2
+        for i in range(128):
+            buf[i] = (i * 7 + 3) & 255
+        return 0
+    def rpe_comm_last_error(self):
+        return b"stub: no librccl"
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+rdv = sharding.Rendezvous(rank, world, tag="t", timeout=20.0, root=os.environ["RPE_TEST_ROOT"])
+out = []
+try:
+    uid = sharding.exchange_unique_id(StubLib(), rdv)
+    out.append("id:" + str(sum(uid)))
+    fail_rank = int(os.environ.get("RPE_TEST_FAIL_PREPARE", "-1"))
+    rdv.agree("prepare", rank != fail_rank, "hipMalloc failed")
+    out.append("prepared")
+    rdv.agree("connect", True)
+    out.append("connected")
+except sharding.CommUnavailable as exc:
+    out.append("unavailable:" + str(exc))
+print("|".join(out), flush=True)
+"""
+
+
+def _run_ranks(tmp_path, style, extra_env=None, world=2):
+    """style 'torchrun': python -m torch.distributed.run starts the ranks (RANK / WORLD_SIZE / MASTER_* / TORCHELASTIC_RUN_ID
+    from the launcher); style 'plain': one subprocess per rank with RANK / WORLD_SIZE and an explicit RPE_COMM_TAG, as under
+    mpirun / srun / a wrapper shell (different parents: nothing may depend on the parent pid)."""
+    script = tmp_path / f"rdv_{style}.py"
+    script.write_text(RDV_WORKER)
+    root = tmp_path / f"root_{style}"
+    env = dict(os.environ, RPE_ROOT=ROOT, RPE_TEST_ROOT=str(root), **(extra_env or {}))
+    if style == "torchrun":
+        logs = tmp_path / f"logs_{style}"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", "29641", "--redirects", "3", "--log-dir", str(logs), str(script)]
+        subprocess.run(cmd, env=env, check=True, timeout=120, capture_output=True)
+        outs = []
+        for r in range(world):
+            f = [p for p in logs.rglob("stdout.log") if f"/{r}/" in str(p)]
+            outs.append(f[0].read_text().strip().splitlines()[-1])
+        return outs
+    procs = []
+    for r in range(world):
+        e = dict(env, RANK=str(r), WORLD_SIZE=str(world), RPE_COMM_TAG="job42")
+        e.pop("TORCHELASTIC_RUN_ID", None)
+        # every rank behind its own wrapper shell: the ranks do NOT share a parent process
+        procs.append(subprocess.Popen(["/bin/sh", "-c", f"exec {sys.executable} {script}"] if r % 2 else [sys.executable, str(script)],
+                                      env=e, stdout=subprocess.PIPE, text=True))
+    return [p.communicate(timeout=120)[0].strip().splitlines()[-1] for p in procs]
+
+
+def test_rendezvous_two_ranks_both_launch_styles(tmp_path):
+    want = "id:" + str(sum((i * 7 + 3) & 255 for i in range(128))) + "|prepared|connected"
+    for style in ("plain", "torchrun"):
+        assert _run_ranks(tmp_path, style) == [want, want], style
+    # the rendezvous directory is private to the user
+    st = os.stat(tmp_path / "root_plain")
+    assert (st.st_mode & 0o077) == 0
+
+
+def test_rendezvous_failures_are_agreed(tmp_path):
+    """a failure on ONE rank is CommUnavailable on ALL ranks -- nobody is left polling or waiting in a collective"""
+    outs = _run_ranks(tmp_path, "plain", {"RPE_TEST_FAIL_ID": "1"})
+    assert all(o.startswith("unavailable:") and "stub: no librccl" in o for o in outs), outs
+    outs = _run_ranks(tmp_path, "plain", {"RPE_TEST_FAIL_PREPARE": "1"})
+    assert all("|unavailable:prepare: rank 1: hipMalloc failed" in o for o in outs), outs
+
+
+def test_bench_refuses_a_mislaunch():
+    """bench.py --gpus N never prints a line for another N: a launcher whose WORLD_SIZE disagrees is an error (without a
+    launcher it starts the N ranks itself -- exercised on the GPU box, bench.self_launch)."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in (p.stderr + p.stdout) and '"n_gpus"' not in p.stdout
+    import bench
+    assert callable(bench.self_launch)
