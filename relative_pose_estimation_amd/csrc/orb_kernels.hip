@@ -624,10 +624,11 @@ __global__ __launch_bounds__(256) void raster_corners_kernel(const unsigned *__r
     }
 }
 
-// retainBest(2 * quota) on the FAST score.  One wave per (level, image); the list sits in LDS and ONE lane replays the
-// runtime library's nth_element + partition on it (retain_best_emul.h) -- the algorithm is a chain of data-dependent
-// swaps, there is nothing for the other 63 lanes to do but the copies in and out.  Two launches share the work by list
-// length (lo < n0 <= cap) so that the common short lists do not reserve the LDS of the longest possible one.
+// retainBest(2 * quota) on the FAST score.  One wave per (level, image); the list sits in LDS and the wave replays the
+// runtime library's nth_element + partition on it (retain_best_emul.h): libstdc++'s partition passes have a closed form
+// that the 64 lanes evaluate with ballots and popcounts (one lane alone spent 2.5 ms per 2048 images chasing dependent
+// LDS round trips); the few-element steps and MSVC's fat-pivot partition run on one lane.  Two launches share the work by
+// list length (lo < n0 <= cap) so that the common short lists do not reserve the LDS of the longest possible one.
 struct FastScoreGT { __device__ __forceinline__ bool operator()(unsigned a, unsigned b) const { return (a >> 24) > (b >> 24); } };
 struct FastScoreGE { __device__ __forceinline__ bool operator()(unsigned a, unsigned b) const { return (a >> 24) >= (b >> 24); } };
 
@@ -635,7 +636,8 @@ __global__ __launch_bounds__(64) void retain_fast_kernel(const unsigned *__restr
                                                           unsigned *__restrict__ cand_xy, int *__restrict__ cand_count,
                                                           unsigned *__restrict__ ovf, RpeDeviceLayout lay, int lo, int cap)
 {
-    extern __shared__ unsigned s_a[];
+    extern __shared__ unsigned s_a[];                          // [cap] elements, then [cap + 2] u16 stopper positions (wave_pair_swap)
+    __shared__ unsigned long long s_mask[2 * 128];           // stopper masks of <= 8192 elements
     __shared__ int s_n1;
     const int lane = threadIdx.x, l = blockIdx.x, img = blockIdx.y;
     const RpeLevel &L = lay.lv[l];
@@ -650,9 +652,13 @@ __global__ __launch_bounds__(64) void retain_fast_kernel(const unsigned *__restr
     if (active) {
         for (int i = lane; i < n0; i += 64) s_a[i] = in[i];
         __syncthreads();
-        if (lane == 0) s_n1 = rb::retain_best(s_a, n0, n_points, lay.stl, FastScoreGT(), FastScoreGE());
-        __syncthreads();
-        n1 = s_n1;
+        if (lay.stl == rb::RT_LIBSTDCXX)                     // the partition passes as ballot / popcount sweeps of the whole wave
+            n1 = rb::wave_retain_best_gnu(s_a, n0, n_points, FastScoreGT(), FastScoreGE(), s_mask, (unsigned short *)(s_a + cap), &s_n1);
+        else {                                               // MSVC's fat-pivot partition: one lane, move for move
+            if (lane == 0) s_n1 = rb::retain_best(s_a, n0, n_points, lay.stl, FastScoreGT(), FastScoreGE());
+            __syncthreads();
+            n1 = s_n1;
+        }
     }
     const int nw = min(n1, L.kcap2);
     for (int i = lane; i < nw; i += 64) {
@@ -681,11 +687,12 @@ void rpe_launch_select(rpe_handle *h, int n_img)
     hipLaunchKernelGGL(raster_corners_kernel, dim3(RPE_NLEVELS, n_img), dim3(256), lds, h->stream,
                        (const unsigned *)h->d_tile_list, (const int *)h->d_tile_cnt,
                        h->d_corner, h->d_corner_count, h->d_ovf, h->lay, h->n_tiles_fast, rows_cap, key_cap);
-    hipLaunchKernelGGL(retain_fast_kernel, dim3(RPE_NLEVELS, n_img), dim3(64), sizeof(unsigned) * (size_t)std::min(ccap_max, RPE_RETAIN_TIER), h->stream,
+    auto lds_of = [](int cap) { return sizeof(unsigned) * (size_t)cap + sizeof(unsigned short) * ((size_t)cap + 4); };
+    hipLaunchKernelGGL(retain_fast_kernel, dim3(RPE_NLEVELS, n_img), dim3(64), lds_of(std::min(ccap_max, RPE_RETAIN_TIER)), h->stream,
                        (const unsigned *)h->d_corner, (const int *)h->d_corner_count, h->d_cand_xy, h->d_cand_count, h->d_ovf, h->lay,
                        0, std::min(ccap_max, RPE_RETAIN_TIER));
     if (nlev_big > 0)
-        hipLaunchKernelGGL(retain_fast_kernel, dim3(nlev_big, n_img), dim3(64), sizeof(unsigned) * (size_t)ccap_max, h->stream,
+        hipLaunchKernelGGL(retain_fast_kernel, dim3(nlev_big, n_img), dim3(64), lds_of(ccap_max), h->stream,
                            (const unsigned *)h->d_corner, (const int *)h->d_corner_count, h->d_cand_xy, h->d_cand_count, h->d_ovf, h->lay,
                            RPE_RETAIN_TIER, ccap_max);
 }
@@ -775,7 +782,8 @@ __global__ __launch_bounds__(64) void retain_harris_kernel(unsigned *__restrict_
                                                             const int *__restrict__ cand_count, int *__restrict__ kp_lvl_count,
                                                             RpeDeviceLayout lay, int lo, int cap)
 {
-    extern __shared__ unsigned long long s_e[];
+    extern __shared__ unsigned long long s_e[];               // [cap] elements, then [cap + 2] u16 stopper positions
+    __shared__ unsigned long long s_mask[2 * 128];
     __shared__ int s_n2;
     const int lane = threadIdx.x, l = blockIdx.x, img = blockIdx.y;
     const RpeLevel &L = lay.lv[l];
@@ -788,9 +796,14 @@ __global__ __launch_bounds__(64) void retain_harris_kernel(unsigned *__restrict_
     float *resp = cand_resp + (long long)img * lay.cand_total + L.cand_off;
     for (int i = lane; i < n1; i += 64) s_e[i] = ((unsigned long long)__float_as_uint(resp[i]) << 32) | xy[i];
     __syncthreads();
-    if (lane == 0) s_n2 = rb::retain_best(s_e, n1, q, lay.stl, HarrisGT(), HarrisGE());
-    __syncthreads();
-    const int n2 = s_n2;
+    int n2;
+    if (lay.stl == rb::RT_LIBSTDCXX)
+        n2 = rb::wave_retain_best_gnu(s_e, n1, q, HarrisGT(), HarrisGE(), s_mask, (unsigned short *)(s_e + cap), &s_n2);
+    else {
+        if (lane == 0) s_n2 = rb::retain_best(s_e, n1, q, lay.stl, HarrisGT(), HarrisGE());
+        __syncthreads();
+        n2 = s_n2;
+    }
     for (int i = lane; i < n2; i += 64) { const unsigned long long e = s_e[i]; xy[i] = (unsigned)e; resp[i] = __uint_as_float((unsigned)(e >> 32)); }
     if (lane == 0) kp_lvl_count[img * RPE_NLEVELS + l] = n2;
 }
@@ -836,10 +849,11 @@ void rpe_launch_keypoints(rpe_handle *h, int n_img)
         if (h->lay.lv[l].kcap2 > RPE_RETAIN_TIER / 2) nlev_big = l + 1;
     }
     const int tier = std::min(kcap2_max, RPE_RETAIN_TIER / 2);
-    hipLaunchKernelGGL(retain_harris_kernel, dim3(RPE_NLEVELS, n_img), dim3(64), sizeof(unsigned long long) * (size_t)tier, h->stream,
+    auto lds_of = [](int cap) { return sizeof(unsigned long long) * (size_t)cap + sizeof(unsigned short) * ((size_t)cap + 4); };
+    hipLaunchKernelGGL(retain_harris_kernel, dim3(RPE_NLEVELS, n_img), dim3(64), lds_of(tier), h->stream,
                        h->d_cand_xy, h->d_cand_resp, (const int *)h->d_cand_count, h->d_kp_lvl_count, h->lay, 0, tier);
     if (nlev_big > 0)
-        hipLaunchKernelGGL(retain_harris_kernel, dim3(nlev_big, n_img), dim3(64), sizeof(unsigned long long) * (size_t)kcap2_max, h->stream,
+        hipLaunchKernelGGL(retain_harris_kernel, dim3(nlev_big, n_img), dim3(64), lds_of(kcap2_max), h->stream,
                            h->d_cand_xy, h->d_cand_resp, (const int *)h->d_cand_count, h->d_kp_lvl_count, h->lay, RPE_RETAIN_TIER / 2, kcap2_max);
     hipLaunchKernelGGL(compact_keypoints_kernel, dim3(n_img), dim3(256), 0, h->stream,
                        (const unsigned *)h->d_cand_xy, (const float *)h->d_cand_resp, (const int *)h->d_kp_lvl_count,

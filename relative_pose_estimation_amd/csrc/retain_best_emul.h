@@ -262,4 +262,125 @@ template <class E, class GT, class GE> RB_FN int retain_best(E *a, int n, int n_
     return partition_pred(a, n_points, n, [&](const E &x) { return ge(x, amb); });
 }
 
+// ================================================================================================ wave-parallel form
+// The two linear passes of the libstdc++ procedure -- __unguarded_partition and std::partition -- are Hoare-style
+// two-pointer scans, and their net effect has a closed form: let A_1 < A_2 < ... be the positions (ascending) where the
+// LEFT scan stops, B_1 > B_2 > ... the positions (descending) where the RIGHT scan stops; the k-th swap exchanges A_k and
+// B_k, for as long as A_k < B_k.  (Each scan only ever looks at positions no swap has touched yet, so A and B can be read
+// off the array as it is before the pass; A_k <= A_K < B_K <= B_k' keeps the swapped sets disjoint even though an element
+// equal to the pivot stops both scans.)  With K = #{k : A_k < B_k}: the pass = those K swaps, and __unguarded_partition
+// returns min(A_{K+1}, B_K) (the left scan rests on the next stopper of the untouched middle or on the element the last swap
+// put at B_K), std::partition returns first + #{pred true}.  K follows from ranks alone: the left stopper at i with rank
+// r is swapped iff at least r right stoppers lie beyond i.  That is a few ballot / popcount sweeps for a wave instead of a
+// chain of dependent LDS round trips for one lane.
+//
+// pair_swap_model: the same arithmetic as the device routine below, lane by lane, on the host -- the unit test compares it
+// with the sequential scans above (tests/test_retain_best_cpu.py), the GPU parity tests compare the device routine with the
+// oracle.  LS(e): the left scan stops at e;  RS(e): the right scan stops at e.
+template <class E, class LS, class RS> RB_FN int pair_swap_model(E *a, int lo, int hi, LS ls, RS rs, int *cut /* A_{K+1}, or hi */)
+{
+    const int m = hi - lo;
+    int totalR = 0;
+    for (int x = lo; x < hi; ++x) totalR += rs(a[x]) ? 1 : 0;
+    // ranks from the ORIGINAL contents
+    int K = 0, rankL = 0, seenR = 0, capK = m / 2 + 1;
+    int *posA = new int[capK + 1], *posB = new int[capK + 1];
+    for (int x = lo; x < hi; ++x) {
+        const bool l = ls(a[x]), r = rs(a[x]);
+        if (r) { ++seenR; const int rr = totalR - seenR + 1; if (rr <= capK) posB[rr - 1] = x; }       // rank from the right
+        if (l) {
+            ++rankL;
+            if (rankL <= capK) posA[rankL - 1] = x;
+            if (totalR - seenR >= rankL) ++K;                                                          // right stoppers strictly beyond x
+        }
+    }
+    for (int k = 0; k < K; ++k) swp(a, posA[k], posB[k]);
+    // where the left scan comes to rest: at the next left stopper of the untouched middle, A_{K+1}, or -- the scans cross
+    // there -- on the element the last swap put at B_K, whichever comes first
+    *cut = K < rankL && K < capK ? posA[K] : hi;
+    if (K >= 1 && posB[K - 1] < *cut) *cut = posB[K - 1];
+    delete[] posA; delete[] posB;
+    return K;
+}
+
+#ifdef __HIPCC__
+// One wave (all 64 lanes, uniform arguments); a[] in LDS; s_mask: 2 x ceil(m / 64) u64 of LDS; s_pos: 2 x (m / 2 + 1) u16 of LDS.
+template <class E, class LS, class RS>
+__device__ __forceinline__ int wave_pair_swap(E *a, int lo, int hi, LS ls, RS rs, unsigned long long *s_mask, unsigned short *s_pos, int &cut)
+{
+    const int lane = threadIdx.x & 63, m = hi - lo, nc = (m + 63) >> 6, capK = m / 2 + 1;
+    unsigned long long *mL = s_mask, *mR = s_mask + nc;
+    unsigned short *posA = s_pos, *posB = s_pos + capK;
+    int totalR = 0, totalL = 0;
+    for (int c = 0; c < nc; ++c) {
+        const int x = lo + 64 * c + lane;
+        bool l = false, r = false;
+        if (x < hi) { const E e = a[x]; l = ls(e); r = rs(e); }
+        const unsigned long long bl = __ballot(l), br = __ballot(r);
+        if (lane == 0) { mL[c] = bl; mR[c] = br; }
+        totalL += __popcll(bl); totalR += __popcll(br);
+    }
+    __syncthreads();
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;        // lanes < lane
+    int K = 0, cumL = 0, cumR = 0;
+    for (int c = 0; c < nc; ++c) {
+        const unsigned long long bl = mL[c], br = mR[c];
+        const int x = lo + 64 * c + lane;
+        const bool l = (bl >> lane) & 1ull, r = (br >> lane) & 1ull;
+        const int rl = cumL + __popcll(bl & below) + 1;                            // rank of this left stopper
+        const int r_le = cumR + __popcll(br & below) + (r ? 1 : 0);                // right stoppers at positions <= x
+        if (r) { const int rr = totalR - r_le + 1; if (rr <= capK) posB[rr - 1] = (unsigned short)x; }
+        bool sw = false;
+        if (l) { if (rl <= capK) posA[rl - 1] = (unsigned short)x; sw = (totalR - r_le) >= rl; }
+        K += __popcll(__ballot(sw));
+        cumL += __popcll(bl); cumR += __popcll(br);
+    }
+    __syncthreads();
+    cut = (K < totalL && K < capK) ? (int)posA[K] : hi;
+    if (K >= 1) cut = min(cut, (int)posB[K - 1]);              // see pair_swap_model
+    for (int k = lane; k < K; k += 64) { const int i = posA[k], j = posB[k]; const E t = a[i]; a[i] = a[j]; a[j] = t; }
+    __syncthreads();
+    return K;
+}
+
+// KeyPointsFilter::retainBest on libstdc++, one wave: the partition passes through wave_pair_swap, the few-element steps
+// (median of three, the <= 3-element insertion sort, the never-taken heap fallback) by lane 0.  Returns the new size (uniform).
+template <class E, class GT, class GE>
+__device__ __forceinline__ int wave_retain_best_gnu(E *a, int n, int n_points, GT gt, GE ge, unsigned long long *s_mask, unsigned short *s_pos, int *s_ctl)
+{
+    if (!(n_points >= 0 && n > n_points)) return n;
+    if (n_points == 0) return 0;
+    const int lane = threadIdx.x & 63, nth = n_points - 1;
+    int first = 0, last = n, depth = 0;
+    for (int m = n; m > 1; m >>= 1) ++depth;
+    depth *= 2;
+    while (last - first > 3) {
+        if (depth == 0) {
+            if (lane == 0) { gnu_heap_select(a, first, nth + 1, last, gt); swp(a, first, nth); }
+            __syncthreads();
+            first = last;                                      // done (the library returns here)
+            break;
+        }
+        --depth;
+        const int mid = first + (last - first) / 2;
+        if (lane == 0) gnu_move_median_to_first(a, first, first + 1, mid, last - 1, gt);
+        __syncthreads();
+        const E pv = a[first];
+        int cut;
+        wave_pair_swap(a, first + 1, last, [&](const E &e) { return !gt(e, pv); }, [&](const E &e) { return !gt(pv, e); }, s_mask, s_pos, cut);
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    if (lane == 0 && last > first) gnu_insertion_sort(a, first, last, gt);
+    __syncthreads();
+    const E amb = a[nth];
+    int cut2, cnt = 0;
+    // std::partition(a + n_points, a + n, e >= amb): the left scan stops at !pred, the right scan at pred
+    for (int x = n_points + lane; x < n; x += 64) cnt += ge(a[x], amb) ? 1 : 0;
+    cnt = wave_sum(cnt);
+    wave_pair_swap(a, n_points, n, [&](const E &e) { return !ge(e, amb); }, [&](const E &e) { return ge(e, amb); }, s_mask, s_pos, cut2);
+    (void)s_ctl;
+    return n_points + cnt;
+}
+#endif
+
 }   // namespace rb

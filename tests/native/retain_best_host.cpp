@@ -49,3 +49,35 @@ extern "C" int rb_heap_path_valid(const float *resp, int n, int nth)
     for (int i = 0; i < n; ++i) if (seen[(size_t)i] != 1) return 0;
     return 1;
 }
+
+// the closed form of the two Hoare-style passes (rb::pair_swap_model = the arithmetic of the wave routine) against the
+// sequential scans: returns 1 when both leave the same array and the same return value
+extern "C" int rb_pairing_equals_sequential(const float *resp, int n, int kind, int arg)
+{
+    std::vector<Kp> a((size_t)n), b((size_t)n);
+    for (int i = 0; i < n; ++i) { a[(size_t)i].response = resp[i]; a[(size_t)i].id = i; }
+    b = a;
+    GT gt; GE ge;
+    int r1, r2;
+    if (kind == 0) {
+        // one introselect round on [0, n): median to first, unguarded partition of [1, n)
+        if (n < 4) return 1;
+        rb::gnu_move_median_to_first(a.data(), 0, 1, n / 2, n - 1, gt);
+        b = a;
+        r1 = rb::gnu_unguarded_partition(a.data(), 1, n, 0, gt);
+        const Kp pv = b[0];
+        rb::pair_swap_model(b.data(), 1, n, [&](const Kp &e) { return !gt(e, pv); }, [&](const Kp &e) { return !gt(pv, e); }, &r2);
+    } else {
+        // std::partition(a + arg, a + n, e >= amb) with amb = a[arg - 1]
+        if (arg < 1 || arg > n) return 1;
+        const Kp amb = a[(size_t)arg - 1];
+        r1 = rb::partition_pred(a.data(), arg, n, [&](const Kp &x) { return ge(x, amb); });
+        int cut;
+        rb::pair_swap_model(b.data(), arg, n, [&](const Kp &e) { return !ge(e, amb); }, [&](const Kp &e) { return ge(e, amb); }, &cut);
+        r2 = arg;
+        for (int i = arg; i < n; ++i) r2 += ge(b[(size_t)i], amb) ? 1 : 0;
+    }
+    if (r1 != r2) return 0;
+    for (int i = 0; i < n; ++i) if (a[(size_t)i].id != b[(size_t)i].id) return 0;
+    return 1;
+}

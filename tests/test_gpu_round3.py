@@ -79,7 +79,7 @@ def test_shard_of_4096_pairs(oracle, K_vga):
     """BASELINE configs[3] gives every GPU 4096 VGA pairs: that shard on ONE GPU -- the workspace for 8192 images is
     allocated, and the results of pair i equal those of the same pair in a 64-pair batch (and the oracle's for a sample)."""
     from relative_pose_estimation_amd import _capi, synthetic
-    i1, i2, _, _ = synthetic.make_batch(64, K_vga, cfg=31)
+    i1, i2, _, _ = synthetic.make_batch(64, K_vga, cfg=7)
     small = _capi.Engine(640, 480, max_batch=64, nfeatures=1000, max_matches=500)
     Rs, ts, inls, nms, sts = small.estimate_batch(i1, i2, K_vga)
     small.close()
@@ -103,7 +103,7 @@ def test_capacity_flags_survive_a_chunked_host_batch(oracle, K_vga):
     reused chunk after chunk, so the flags are collected per pair as the chunks finish: a dots image (thousands of tied
     FAST scores) in the middle of chunk 1 still reports its truncation, nobody else does."""
     from relative_pose_estimation_amd import _capi, synthetic
-    i1, i2, _, _ = synthetic.make_batch(8, K_vga, cfg=33)
+    i1, i2, _, _ = synthetic.make_batch(8, K_vga, cfg=8)
     a = np.tile(i1, (64, 1, 1)); b = np.tile(i2, (64, 1, 1))
     dots = np.full((480, 640), 40, np.uint8)
     dots[40:440:8, 40:600:8] = 220

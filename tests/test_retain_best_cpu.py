@@ -70,3 +70,19 @@ def test_heap_select_branch(lib):
         for nkeys in (0, 4):
             resp = rng.random(n).astype(np.float32) if nkeys == 0 else rng.integers(0, nkeys, n).astype(np.float32)
             assert lib.rb_heap_path_valid(resp.ctypes.data_as(C.c_void_p), n, nth) == 1
+
+
+def test_closed_form_of_the_partition_passes(lib):
+    """wave_pair_swap's arithmetic (ranks of the left / right stoppers, K swaps, return value), run lane by lane on the
+    host (rb::pair_swap_model), against the sequential two-pointer scans it replaces on the GPU"""
+    rng = np.random.default_rng(21)
+    n_cases = 0
+    for n in [4, 5, 6, 9, 63, 64, 65, 130, 500, 1614, 4800]:
+        for nkeys in [1, 2, 3, 7, 40, 0]:
+            for _ in range(6):
+                resp = rng.random(n).astype(np.float32) if nkeys == 0 else rng.integers(15, 15 + nkeys, n).astype(np.float32)
+                assert lib.rb_pairing_equals_sequential(resp.ctypes.data_as(C.c_void_p), n, 0, 0) == 1, (n, nkeys, "unguarded_partition")
+                arg = int(rng.integers(1, n + 1))
+                assert lib.rb_pairing_equals_sequential(resp.ctypes.data_as(C.c_void_p), n, 1, arg) == 1, (n, nkeys, arg, "partition")
+                n_cases += 2
+    assert n_cases > 700
