@@ -454,6 +454,62 @@ def run_workload(args, method, sub, data, rank, world, device, comm_kind):
     return out
 
 
+def dropin_operating_points(data, device, workers):
+    """The drop-in's own operating points, driver-timed in the same run (rank 0, N = 1):
+    single_pair: PoseEstimator.estimate(img1, img2) -- host images in, (R, t) out -- at the reference's defaults (ORB 4000,
+      top-500: src/run_single_pair.py:49-57), 640x480 and 1920x1080, median of 30 calls;
+    host_entry: rpe_estimate_batch on the 1024 headline pairs held in HOST memory (the boundary the reference's callers see,
+      src/utils/image_loader.py:23-28): pageable numpy arrays and page-locked ones (Engine.pinned_empty), uploads pipelined
+      behind the kernels in four chunks; the device-resident rate is the headline `value`."""
+    import statistics
+    from relative_pose_estimation_amd import PoseEstimator, _capi, geometry, synthetic
+    out = {"single_pair": {}, "host_entry": {}}
+    for (W, H) in ((640, 480), (1920, 1080)):
+        K = geometry.default_camera_matrix(W, H)
+        i1, i2, _, _ = synthetic.make_batch(1, K, W, H, cfg=5, workers=1)
+        pe = PoseEstimator(K, device=device)                      # reference defaults: ORB, Hamming, nfeatures 4000, max_matches 500
+        for _ in range(3):
+            pe.estimate(i1[0], i2[0])
+        ts = []
+        for _ in range(30):
+            t0 = time.perf_counter(); pe.estimate(i1[0], i2[0]); ts.append(time.perf_counter() - t0)
+        eng = pe._engine(H, W, 1)
+        eng.set_profiling(True); pe.estimate(i1[0], i2[0])
+        out["single_pair"][f"{W}x{H}"] = {"ms_per_estimate_call": round(statistics.median(ts) * 1e3, 3), "min_ms": round(min(ts) * 1e3, 3),
+                                          "config": "PoseEstimator(K).estimate(img1, img2): ORB 4000, Hamming crossCheck, top-500, host images in, (R, t) out",
+                                          "stage_ms": {k: round(v, 3) for k, v in eng.stage_ms().items() if v > 0.0005}}
+        pe.close()
+    K, i1, i2 = data["K"], data["i1"], data["i2"]
+    B, H, W = i1.shape
+    e = _capi.Engine(W, H, max_batch=B, nfeatures=1000, max_matches=500, device=device)
+    p1 = e.pinned_empty(i1.shape); p2 = e.pinned_empty(i2.shape)
+    p1[...] = i1; p2[...] = i2
+    nbytes = 2 * i1.nbytes
+    for name, (a, b) in (("pageable", (i1, i2)), ("pinned", (p1, p2))):
+        for _ in range(2):
+            e.estimate_batch(a, b, K)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            e.estimate_batch(a, b, K)
+        dt = (time.perf_counter() - t0) / 5
+        out["host_entry"][name] = {"pairs_per_s": round(B / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "host_bytes_per_batch": int(nbytes),
+                                   "h2d_gbs_if_serial": round(nbytes / dt / 1e9, 2)}
+    # the upload alone, for the H2D share
+    d = e.device_malloc(i1.nbytes)
+    for name, a in (("pageable", i1), ("pinned", p1)):
+        e.lib.rpe_memcpy_h2d(e.h, d, a.ctypes.data_as(__import__("ctypes").c_void_p), a.nbytes)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            e.lib.rpe_memcpy_h2d(e.h, d, a.ctypes.data_as(__import__("ctypes").c_void_p), a.nbytes)
+        dt = (time.perf_counter() - t0) / 3
+        out["host_entry"][name]["h2d_alone_ms_per_batch"] = round(2 * dt * 1e3, 3)
+        out["host_entry"][name]["h2d_alone_gbs"] = round(a.nbytes / dt / 1e9, 2)
+    e.device_free(d)
+    e.close()
+    out["host_entry"]["note"] = "1024 VGA pairs = 629 MB per batch; PCIe Gen5 x16 ~ 63 GB/s = 10 ms = a ceiling of ~100 k pairs/s for this entry"
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver would
     (python -m torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1), as a CHILD process -- nothing in this
@@ -523,6 +579,11 @@ def main():
             o = run_workload(a, m, s, d, 0, 1, device, "rccl")
             out["extra"][name] = {k: o[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "median_rotation_error_deg", "pairs_ok",
                                                     "stage_ms_per_launch", "roofline", "cpu_baseline") if k in o}
+    if rank == 0 and want_extra:
+        try:
+            out["extra"].update(dropin_operating_points(data, device, workers))
+        except Exception as exc:                   # never lose the headline line to an extra
+            out["extra"]["dropin_operating_points_error"] = repr(exc)
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -145,6 +145,13 @@ int rpe_device_free(rpe_handle *h, void *d_ptr);
 int rpe_memcpy_h2d(rpe_handle *h, void *d_dst, const void *h_src, size_t bytes);
 int rpe_memcpy_d2h(rpe_handle *h, void *h_dst, const void *d_src, size_t bytes);
 int rpe_synchronize(rpe_handle *h);
+/* page-locked host memory for image batches handed to rpe_estimate_batch / rpe_estimate_stream (the reference's callers
+ * hold numpy arrays from cv2.imread, src/utils/image_loader.py:23-28): uploads from pinned memory do not block the
+ * calling thread and run at the full PCIe rate.  rpe_host_register pins a buffer the caller already owns. */
+int rpe_host_alloc(rpe_handle *h, size_t bytes, void **h_ptr);
+int rpe_host_free(rpe_handle *h, void *h_ptr);
+int rpe_host_register(rpe_handle *h, void *h_ptr, size_t bytes);
+int rpe_host_unregister(rpe_handle *h, void *h_ptr);
 
 /* ------------------------------------------------------------- hot path */
 /* replaces PoseEstimator.estimate (pose_estimator.py:487-533) for B pairs.

@@ -28,7 +28,7 @@ ORDER_BGR, ORDER_RGB = 0, 1
 EXPORTS = [
     "rpe_default_config", "rpe_create", "rpe_destroy", "rpe_last_error", "rpe_device_count",
     "rpe_keypoint_capacity", "rpe_device_malloc", "rpe_device_free", "rpe_memcpy_h2d", "rpe_memcpy_d2h",
-    "rpe_synchronize", "rpe_estimate_batch", "rpe_estimate_batch_device", "rpe_enqueue_batch_device",
+    "rpe_synchronize", "rpe_host_alloc", "rpe_host_free", "rpe_host_register", "rpe_host_unregister", "rpe_estimate_batch", "rpe_estimate_batch_device", "rpe_enqueue_batch_device",
     "rpe_fetch_results", "rpe_fetch_matched_points", "rpe_orb_detect_and_compute", "rpe_orb_debug_fetch",
     "rpe_orb_pyramid_pixels", "rpe_match_hamming", "rpe_find_essential", "rpe_recover_pose",
     "rpe_set_profiling", "rpe_get_stage_ms", "rpe_stage_name",
@@ -79,6 +79,10 @@ def load():
     lib.rpe_device_count.argtypes = []; lib.rpe_device_count.restype = C.c_int
     lib.rpe_keypoint_capacity.argtypes = [vp]; lib.rpe_keypoint_capacity.restype = C.c_int
     lib.rpe_device_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]; lib.rpe_device_malloc.restype = C.c_int
+    lib.rpe_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]; lib.rpe_host_alloc.restype = C.c_int
+    lib.rpe_host_free.argtypes = [vp, vp]; lib.rpe_host_free.restype = C.c_int
+    lib.rpe_host_register.argtypes = [vp, vp, C.c_size_t]; lib.rpe_host_register.restype = C.c_int
+    lib.rpe_host_unregister.argtypes = [vp, vp]; lib.rpe_host_unregister.restype = C.c_int
     lib.rpe_device_free.argtypes = [vp, vp]; lib.rpe_device_free.restype = C.c_int
     lib.rpe_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]; lib.rpe_memcpy_h2d.restype = C.c_int
     lib.rpe_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]; lib.rpe_memcpy_d2h.restype = C.c_int
@@ -175,6 +179,7 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None):
+            self.free_pinned()
             self.lib.rpe_destroy(self.h)
             self.h = None
 
@@ -196,6 +201,23 @@ class Engine:
 
     def device_free(self, p):
         self._chk(self.lib.rpe_device_free(self.h, p))
+
+    def pinned_empty(self, shape, dtype=np.uint8):
+        """numpy array on page-locked host memory (rpe_host_alloc): image batches for estimate_batch / estimate_stream that
+        upload without blocking and at the full PCIe rate.  Freed with the engine (or free_pinned)."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._chk(self.lib.rpe_host_alloc(self.h, n, C.byref(p)))
+        buf = (C.c_uint8 * n).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        return arr
+
+    def free_pinned(self):
+        for p in getattr(self, "_pinned", []):
+            self.lib.rpe_host_free(self.h, p)
+        self._pinned = []
 
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)

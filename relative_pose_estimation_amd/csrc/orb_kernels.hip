@@ -634,18 +634,23 @@ struct FastScoreGE { __device__ __forceinline__ bool operator()(unsigned a, unsi
 
 __global__ __launch_bounds__(64) void retain_fast_kernel(const unsigned *__restrict__ corner, const int *__restrict__ corner_count,
                                                           unsigned *__restrict__ cand_xy, int *__restrict__ cand_count,
-                                                          unsigned *__restrict__ ovf, RpeDeviceLayout lay, int lo, int cap)
+                                                          unsigned *__restrict__ ovf, RpeDeviceLayout lay, int lo, int cap, int n_img)
 {
     extern __shared__ unsigned s_a[];                          // [cap] elements, then [cap + 2] u16 stopper positions (wave_pair_swap)
     __shared__ unsigned long long s_mask[2 * 128];           // stopper masks of <= 8192 elements
     __shared__ int s_n1;
-    const int lane = threadIdx.x, l = blockIdx.x, img = blockIdx.y;
+    const int lane = threadIdx.x, l = blockIdx.x;
     const RpeLevel &L = lay.lv[l];
+    // the long-list launch runs a small grid whose workgroups walk over the images: on ordinary images it has nothing to do,
+    // and 10 000 empty workgroups that each reserve 26 KB of LDS took 64 us
+#pragma unroll 1
+    for (int img = blockIdx.y; img < n_img; img += gridDim.y) {
+    __syncthreads();
     const int n0 = corner_count[img * RPE_NLEVELS + l];
     const int n_points = 2 * L.quota;
     const bool active = n0 > n_points;                       // retainBest does nothing otherwise (the list stays in raster order)
     // the pass-through lists belong to the first launch (lo == 0)
-    if (active ? !(n0 > lo && n0 <= cap) : lo != 0) return;
+    if (active ? !(n0 > lo && n0 <= cap) : lo != 0) continue;
     const unsigned *in = corner + (long long)img * lay.corner_total + L.corner_off;
     unsigned *out = cand_xy + (long long)img * lay.cand_total + L.cand_off;
     int n1 = n0;
@@ -669,6 +674,7 @@ __global__ __launch_bounds__(64) void retain_fast_kernel(const unsigned *__restr
         cand_count[img * RPE_NLEVELS + l] = nw;
         if (n1 > L.kcap2) atomicOr(&ovf[img], (unsigned)RPE_OVF_ORB_CANDIDATES);
     }
+    }
 }
 
 #define RPE_RETAIN_TIER 2048         // list length served by the small-LDS launch of the two retain kernels
@@ -690,11 +696,11 @@ void rpe_launch_select(rpe_handle *h, int n_img)
     auto lds_of = [](int cap) { return sizeof(unsigned) * (size_t)cap + sizeof(unsigned short) * ((size_t)cap + 4); };
     hipLaunchKernelGGL(retain_fast_kernel, dim3(RPE_NLEVELS, n_img), dim3(64), lds_of(std::min(ccap_max, RPE_RETAIN_TIER)), h->stream,
                        (const unsigned *)h->d_corner, (const int *)h->d_corner_count, h->d_cand_xy, h->d_cand_count, h->d_ovf, h->lay,
-                       0, std::min(ccap_max, RPE_RETAIN_TIER));
+                       0, std::min(ccap_max, RPE_RETAIN_TIER), n_img);
     if (nlev_big > 0)
-        hipLaunchKernelGGL(retain_fast_kernel, dim3(nlev_big, n_img), dim3(64), lds_of(ccap_max), h->stream,
+        hipLaunchKernelGGL(retain_fast_kernel, dim3(nlev_big, std::min(n_img, 256)), dim3(64), lds_of(ccap_max), h->stream,
                            (const unsigned *)h->d_corner, (const int *)h->d_corner_count, h->d_cand_xy, h->d_cand_count, h->d_ovf, h->lay,
-                           RPE_RETAIN_TIER, ccap_max);
+                           RPE_RETAIN_TIER, ccap_max, n_img);
 }
 
 // ----------------------------------------------------------------- harris

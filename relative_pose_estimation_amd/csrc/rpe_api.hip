@@ -418,6 +418,32 @@ extern "C" int rpe_device_free(rpe_handle *h, void *d_ptr)
     h->err = "rpe_device_free: unknown pointer";
     return RPE_ERR_INVALID;
 }
+extern "C" int rpe_host_alloc(rpe_handle *h, size_t bytes, void **h_ptr)
+{
+    if (!h || !h_ptr) return RPE_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipHostMalloc(h_ptr, bytes, hipHostMallocDefault));
+    return RPE_OK;
+}
+extern "C" int rpe_host_free(rpe_handle *h, void *h_ptr)
+{
+    if (!h) return RPE_ERR_INVALID;
+    HIPCHK(h, hipHostFree(h_ptr));
+    return RPE_OK;
+}
+extern "C" int rpe_host_register(rpe_handle *h, void *h_ptr, size_t bytes)
+{
+    if (!h || !h_ptr) return RPE_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipHostRegister(h_ptr, bytes, hipHostRegisterDefault));
+    return RPE_OK;
+}
+extern "C" int rpe_host_unregister(rpe_handle *h, void *h_ptr)
+{
+    if (!h || !h_ptr) return RPE_ERR_INVALID;
+    HIPCHK(h, hipHostUnregister(h_ptr));
+    return RPE_OK;
+}
 extern "C" int rpe_memcpy_h2d(rpe_handle *h, void *d, const void *s, size_t n)
 {
     if (!h) return RPE_ERR_INVALID;
