@@ -35,7 +35,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 me
 VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2
 # dense int8 MFMA peak: 2x the bf16 rate per clock (MI355X_MICROARCH.md 'Matrix cores'), bf16 dense ~2.5 PFLOP/s
 MFMA_I8_PEAK_TOPS = 5000.0
-COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")
+COUNTERS = os.path.join(ROOT, "profiles", "r03_counters.json")
+if not os.path.exists(COUNTERS):
+    COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")
 
 
 def orb_levels(W, H, nlevels=12, scale=1.1):
@@ -109,7 +111,7 @@ def stage_bytes(stage, W, H, pyr_px, nkp, mm, method="ORB"):
 
 
 STAGE_KERNEL = {"pyramid": "pyr_resize_kernel", "fast": "fast_nms_kernel", "angle": "orient_describe_kernel",
-                "select": "select_candidates_kernel", "harris": "harris_kernel", "keypoints": "select_keypoints_kernel",
+                "select": "raster_corners_kernel + retain_fast_kernel", "harris": "harris_kernel", "keypoints": "retain_harris_kernel + compact_keypoints_kernel",
                 "match": "match_hamming_mfma_kernel", "ransac": "ransac_*_kernel (group)", "pose": "recover_pose_kernel"}
 # SIFT reuses the stage slots (csrc/sift_kernels.hip rpe_sift_run)
 SIFT_STAGE_KERNEL = {"pyramid": "sift_blur_fused_kernel", "fast": "sift_extrema_mask_kernel",
@@ -117,12 +119,12 @@ SIFT_STAGE_KERNEL = {"pyramid": "sift_blur_fused_kernel", "fast": "sift_extrema_
                      "describe": "sift_describe_kernel", "match": "match_l2_nearest_kernel",
                      "ransac": "ransac_*_kernel (group)", "pose": "recover_pose_kernel"}
 # instruction kind of rpe_calibrate_valu that a stage's inner loop is made of (the measured issue roof it is priced against)
-STAGE_CALIB_KIND = {"fast": 4, "pyramid": 5, "angle": 3, "match": 0, "ransac": 6, "pose": 6, "harris": 5, "select": 5, "keypoints": 5,
+STAGE_CALIB_KIND = {"fast": 4, "pyramid": 5, "angle": 3, "match": 3, "ransac": 6, "pose": 6, "harris": 5, "select": 5, "keypoints": 5,
                     "describe": 5, "nms": 5, "blur": 5}
 
 
 def counters_for(workload_key):
-    """Per-kernel PMC numbers of the committed rocprofv3 passes (profiles/r02_counters.json, written by
+    """Per-kernel PMC numbers of the committed rocprofv3 passes (profiles/r03_counters.json, written by
     profiles/make_counters.py from separate --pmc runs: FETCH_SIZE, WRITE_SIZE, SQ_*): HBM bytes per launch
     (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) and SQ_INSTS_VALU per launch, or {} when no profile exists for
     this workload."""

@@ -176,9 +176,14 @@ __device__ __forceinline__ v4i_t expand16(unsigned b)
     return r;
 }
 
+// SPLIT = true: small batches (the drop-in's estimate() is a batch of ONE pair: a single workgroup walked 2 x 127 x 127 tiles
+// alone, 2.3 ms of a 2.9 ms call).  The rounds of 8 owner tiles are dealt over gridDim.y workgroups per pair, the election
+// words live in HBM (integer atomicMin: order independent), and match_hamming_select_kernel sorts and emits afterwards.
+template <bool SPLIT>
 __global__ __launch_bounds__(MM_NT) void match_hamming_mfma_kernel(const uint8_t *__restrict__ desc, const int *__restrict__ kp_count,
                                                                     const float2 *__restrict__ kp_pt, int img2_base, int kcap,
                                                                     int max_matches, int region0,
+                                                                    unsigned *__restrict__ g_best, unsigned *__restrict__ g_row,
                                                                     int *__restrict__ m_q, int *__restrict__ m_t, int *__restrict__ m_d,
                                                                     int *__restrict__ m_n, float2 *__restrict__ pts1, float2 *__restrict__ pts2)
 {
@@ -187,13 +192,13 @@ __global__ __launch_bounds__(MM_NT) void match_hamming_mfma_kernel(const uint8_t
     // words + the popcounts; reused as the sort-key array afterwards.  Then kcap election words and kcap own-nearest words.
     v4i_t *s_a = (v4i_t *)s_dyn;                               // [2][8][64]
     unsigned *s_qpk = (unsigned *)(s_dyn + 2 * 8 * 64);        // [2][32]
-    unsigned *s_best = (unsigned *)(s_dyn + region0);          // kcap entries
-    unsigned *s_row = s_best + kcap;                           // kcap entries: the query's own nearest train (second crossCheck pass)
-    __shared__ int s_valid;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pair = blockIdx.x;
+    unsigned *s_best = SPLIT ? g_best + (long long)pair * kcap : (unsigned *)(s_dyn + region0);          // kcap entries
+    unsigned *s_row = SPLIT ? g_row + (long long)pair * kcap : s_best + kcap;     // kcap entries: the query's own nearest train (second crossCheck pass)
+    __shared__ int s_valid;
     const int img1 = pair, img2 = img2_base + pair;
     const int n1 = min(kp_count[img1], kcap), n2 = min(kp_count[img2], kcap);
-    for (int i = tid; i < n1; i += MM_NT) { s_best[i] = 0xFFFFFFFFu; s_row[i] = 0xFFFFFFFEu; }
+    if (!SPLIT) for (int i = tid; i < n1; i += MM_NT) { s_best[i] = 0xFFFFFFFFu; s_row[i] = 0xFFFFFFFEu; }      // SPLIT: the host memsets them
     if (tid == 0) s_valid = 0;
     // |x| + 512 of every scanned descriptor, once per pass (the passes over the scanned tiles all need them); kept in the free
     // part of the first 32 KB (kcap <= 8064 entries)
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(MM_NT) void match_hamming_mfma_kernel(const uint8_t
         s_qpop[i] = (unsigned short)(512u + __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w));
     }
     const int ntq = (n_scan + 31) >> 5, ntt = (n_own + 31) >> 5;
-    for (int tt0 = 0; tt0 < ntt && n_scan > 0; tt0 += 8) {
+    for (int tt0 = SPLIT ? 8 * (int)blockIdx.y : 0; tt0 < ntt && n_scan > 0; tt0 += SPLIT ? 8 * (int)gridDim.y : 8) {
         const int tt = tt0 + wv;                               // wave-uniform
         const int j = tt * 32 + col;
         const bool valid_t = tt < ntt && j < n_own;
@@ -288,6 +293,63 @@ __global__ __launch_bounds__(MM_NT) void match_hamming_mfma_kernel(const uint8_t
     }
     }
     __syncthreads();
+    if (SPLIT) return;
+    // (dist, queryIdx) keys; unmatched queries sort to the end -- same epilogue as the VALU kernel
+    int sortP = 64;
+    while (sortP < n1) sortP <<= 1;
+    unsigned *s_key = (unsigned *)s_dyn;
+    int myvalid = 0;
+    for (int i = tid; i < sortP; i += MM_NT) {
+        unsigned key = 0xFFFFFFFFu;
+        if (i < n1) {
+            unsigned b = s_best[i];
+            if (b != 0xFFFFFFFFu && b == s_row[i]) { key = ((b >> 18) << 16) | (unsigned)i; ++myvalid; }
+        }
+        s_key[i] = key;
+    }
+    if (myvalid) atomicAdd(&s_valid, myvalid);
+    __syncthreads();
+    for (int k = 2; k <= sortP; k <<= 1) {
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int t = tid; t < (sortP >> 1); t += MM_NT) {
+                int i = 2 * jj * (t / jj) + (t % jj);
+                int ixj = i + jj;
+                bool asc = (i & k) == 0;
+                unsigned a = s_key[i], b = s_key[ixj];
+                if ((a > b) == asc) { s_key[i] = b; s_key[ixj] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const int nm = min(s_valid, max_matches);
+    for (int r = tid; r < nm; r += MM_NT) {
+        unsigned key = s_key[r];
+        int i = key & 0xFFFF, d = key >> 16;
+        int j = s_best[i] & 0x3FFFF;
+        long long o = (long long)pair * max_matches + r;
+        m_q[o] = i; m_t[o] = j; m_d[o] = d;
+        pts1[o] = kp_pt[(long long)img1 * kcap + i];
+        pts2[o] = kp_pt[(long long)img2 * kcap + j];
+    }
+    if (tid == 0) m_n[pair] = nm;
+}
+
+
+// sort + top-max_matches + point gather of a SPLIT run (one workgroup per pair; the same steps as the fused epilogue)
+__global__ __launch_bounds__(MM_NT) void match_hamming_select_kernel(const unsigned *__restrict__ g_best, const unsigned *__restrict__ g_row,
+                                                                      const int *__restrict__ kp_count, const float2 *__restrict__ kp_pt,
+                                                                      int img2_base, int kcap, int max_matches,
+                                                                      int *__restrict__ m_q, int *__restrict__ m_t, int *__restrict__ m_d,
+                                                                      int *__restrict__ m_n, float2 *__restrict__ pts1, float2 *__restrict__ pts2)
+{
+    extern __shared__ uint4 s_dyn[];
+    __shared__ int s_valid;
+    const int tid = threadIdx.x, pair = blockIdx.x;
+    const int img1 = pair, img2 = img2_base + pair;
+    const int n1 = min(kp_count[img1], kcap);
+    const unsigned *s_best = g_best + (long long)pair * kcap, *s_row = g_row + (long long)pair * kcap;
+    if (tid == 0) s_valid = 0;
+    __syncthreads();
     // (dist, queryIdx) keys; unmatched queries sort to the end -- same epilogue as the VALU kernel
     int sortP = 64;
     while (sortP < n1) sortP <<= 1;
@@ -345,9 +407,22 @@ void rpe_launch_match(rpe_handle *h, int B)
         int sortP = 64;
         while (sortP < kcap) sortP <<= 1;
         const size_t r0 = (std::max((size_t)(2 * 8 * 64 + 16) * 16 + (size_t)kcap * 2, (size_t)sortP * 4) + 15) / 16;
-        hipLaunchKernelGGL(match_hamming_mfma_kernel, dim3(B), dim3(MM_NT), r0 * 16 + (size_t)kcap * 8, h->stream,
-                           h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches, (int)r0,
-                           h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
+        const int rounds = ((kcap + 31) / 32 + 7) / 8;
+        const int split = B <= RPE_MATCH_SPLIT_PAIRS ? std::min(rounds, std::max(1, 256 / B)) : 1;
+        if (split > 1) {
+            hipMemsetAsync(h->d_hm_best, 0xFF, sizeof(unsigned) * (size_t)B * kcap, h->stream);
+            hipMemsetAsync(h->d_hm_row, 0xFE, sizeof(unsigned) * (size_t)B * kcap, h->stream);
+            hipLaunchKernelGGL((match_hamming_mfma_kernel<true>), dim3(B, split), dim3(MM_NT), r0 * 16, h->stream,
+                               h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches, (int)r0,
+                               h->d_hm_best, h->d_hm_row, h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
+            hipLaunchKernelGGL(match_hamming_select_kernel, dim3(B), dim3(MM_NT), (size_t)sortP * 4, h->stream,
+                               (const unsigned *)h->d_hm_best, (const unsigned *)h->d_hm_row, h->d_kp_count, h->d_kp_pt,
+                               h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches,
+                               h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
+        } else
+            hipLaunchKernelGGL((match_hamming_mfma_kernel<false>), dim3(B), dim3(MM_NT), r0 * 16 + (size_t)kcap * 8, h->stream,
+                               h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches, (int)r0,
+                               (unsigned *)nullptr, (unsigned *)nullptr, h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
     }
 }
 

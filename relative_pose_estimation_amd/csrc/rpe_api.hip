@@ -316,6 +316,7 @@ static int alloc_workspace(rpe_handle *h)
     HIPCHK(h, hipHostMalloc((void **)&h->h_resblk, (size_t)B * RPE_RESULT_BYTES));
     DM(h, h->d_pts1, B * mm); DM(h, h->d_pts2, B * mm);
     if (h->cfg.norm_type == RPE_NORM_L2) { DM(h, h->d_m_best, B * L.kcap); DM(h, h->d_m_best2, B * L.kcap); }
+    else { const size_t bs = B < RPE_MATCH_SPLIT_PAIRS ? B : RPE_MATCH_SPLIT_PAIRS; DM(h, h->d_hm_best, bs * L.kcap); DM(h, h->d_hm_row, bs * L.kcap); }
     DM(h, h->d_n1, B * mm); DM(h, h->d_n2, B * mm);
     DM(h, h->d_rstate, B); DM(h, h->d_found, B);
     DM(h, h->d_models, B * RPE_RANSAC_MAXCHUNK * RPE_MAX_MODELS * 9);
@@ -390,7 +391,7 @@ extern "C" void rpe_destroy(rpe_handle *h)
                     h->d_hist, h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_angle,
                     h->d_kp_pt, h->d_kp_cs, h->d_kp_count, h->d_desc, h->d_m_q, h->d_m_t, h->d_m_d, h->d_resblk, h->d_pts1, h->d_pts2,
                     h->d_subsets, h->d_nit_denom, h->d_nit_round, h->d_rstate, h->d_n1, h->d_n2, h->d_found, h->d_models, h->d_hyp, h->d_counts,
-                    h->d_nmodels, h->d_mask, h->d_E, h->d_K, h->d_m_best, h->d_m_best2, h->d_ovf, h->d_corner, h->d_corner_count, h->d_kp_lvl_count};
+                    h->d_nmodels, h->d_mask, h->d_E, h->d_K, h->d_m_best, h->d_m_best2, h->d_hm_best, h->d_hm_row, h->d_ovf, h->d_corner, h->d_corner_count, h->d_kp_lvl_count};
     for (void *p : ptrs) if (p) hipFree(p);
     if (h->h_resblk) hipHostFree(h->h_resblk);
     for (void *p : h->user_allocs) hipFree(p);
@@ -737,27 +738,45 @@ extern "C" int rpe_estimate_batch(rpe_handle *h, const uint8_t *h_imgs1, const u
         HIPCHK(h, hipEventRecord(h->ev_up[c], h->copy_stream));
         return RPE_OK;
     };
-    // copies from pageable host memory block the calling thread, so the order of the host calls is the pipeline:
-    // kernels of chunk c are queued BEFORE the upload of chunk c+1 is issued, results of c are fetched after it
+    // The chunks run back to back on the compute stream without a host round trip in between: chunk c's results (and capacity
+    // flags) are copied device-to-device into a whole-batch block right behind its kernels, the next upload is issued while
+    // they run, and the host waits ONCE, at the end (a fetch per chunk cost four stream drains per batch).  Copies from
+    // pageable host memory still block the calling thread while they are staged -- after the kernels of the chunk before
+    // have been queued; page-locked batches (rpe_host_alloc / rpe_host_register) do not block at all.
+    if (!h->d_resall) {
+        const size_t MBb = (size_t)h->cfg.max_batch;
+        HIPCHK(h, hipMalloc((void **)&h->d_resall, MBb * RPE_RESULT_BYTES));
+        HIPCHK(h, hipMalloc((void **)&h->d_ovfall, MBb * 2 * sizeof(unsigned)));
+        h->user_allocs.push_back(h->d_resall); h->user_allocs.push_back(h->d_ovfall);
+    }
+    const size_t MB = (size_t)h->cfg.max_batch;
+    const size_t soff[5] = {0, MB * 72, MB * 96, MB * 100, MB * 104}, esz[5] = {72, 24, 4, 4, 4};
     int rc = upload(0);
     if (rc) return rc;
-    h->ovf_pairs.assign((size_t)B, 0u);
-    std::vector<unsigned> ov;
     for (int c = 0; c < nchunks; ++c) {
         const int off = c * per, n = B - off < per ? B - off : per;
         if (n <= 0) break;
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_up[c], 0));
         if ((rc = rpe_enqueue_batch_device(h, h->d_stage1 + (size_t)off * img, h->d_stage2 + (size_t)off * img, n, K)) != RPE_OK) return rc;
+        for (int k = 0; k < 5; ++k)
+            HIPCHK(h, hipMemcpyAsync(h->d_resall + soff[k] + (size_t)off * esz[k], h->d_resblk + soff[k], (size_t)n * esz[k], hipMemcpyDeviceToDevice, h->stream));
+        // the chunk's capacity flags (image slots p and img2_base + p of this launch), before the next chunk overwrites them
+        HIPCHK(h, hipMemcpyAsync(h->d_ovfall + off, h->d_ovf, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_ovfall + MB + off, h->d_ovf + h->last_img2_base, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
         if (c + 1 < nchunks && (rc = upload(c + 1)) != RPE_OK) return rc;
-        rc = rpe_fetch_results(h, n, R ? R + 9 * (size_t)off : nullptr, t ? t + 3 * (size_t)off : nullptr,
-                               inliers ? inliers + off : nullptr, n_matches ? n_matches + off : nullptr, status ? status + off : nullptr);
-        if (rc) return rc;
-        // the chunk's capacity flags (image slots p and n + p of this launch), before the next chunk overwrites them
-        ov.resize((size_t)h->last_img2_base + n);
-        HIPCHK(h, hipMemcpyAsync(ov.data(), h->d_ovf, sizeof(unsigned) * ov.size(), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        for (int p2 = 0; p2 < n; ++p2) h->ovf_pairs[(size_t)off + p2] = ov[p2] | ov[(size_t)h->last_img2_base + p2];
     }
+    std::vector<unsigned> ov(2 * MB);
+    HIPCHK(h, hipMemcpyAsync(h->h_resblk, h->d_resall, MB * RPE_RESULT_BYTES, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(ov.data(), h->d_ovfall, sizeof(unsigned) * 2 * MB, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint8_t *o = h->h_resblk;
+    if (R) memcpy(R, o, (size_t)B * 72);
+    if (t) memcpy(t, o + MB * 72, (size_t)B * 24);
+    if (inliers) memcpy(inliers, o + MB * 96, (size_t)B * 4);
+    if (status) memcpy(status, o + MB * 100, (size_t)B * 4);
+    if (n_matches) memcpy(n_matches, o + MB * 104, (size_t)B * 4);
+    h->ovf_pairs.assign((size_t)B, 0u);
+    for (int p2 = 0; p2 < B; ++p2) h->ovf_pairs[(size_t)p2] = ov[(size_t)p2] | ov[MB + (size_t)p2];
     h->last_chunked = true;
     return RPE_OK;
 }

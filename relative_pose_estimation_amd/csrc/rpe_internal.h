@@ -13,6 +13,7 @@
 #define RPE_RANSAC_CHUNK 64    // solver wave granularity: 64 RANSAC iterations per wave
 #define RPE_RANSAC_MAXCHUNK 512 // largest number of iterations evaluated per launch group (8 waves per pair)
 #define RPE_MAX_MODELS 10
+#define RPE_MATCH_SPLIT_PAIRS 64   // batches up to this many pairs split a pair's Hamming matching over several workgroups
 #define RPE_RESULT_BYTES 108     // per pair: R 72 + t 24 + inliers 4 + status 4 + n_matches 4
 // FAST tile = 64 x FAST_TH output pixels, FAST_TH * 4 threads.  Unlike the resize kernel (latency bound: smaller tiles
 // won), FAST is bound by instruction issue and 32-row tiles with two waves only add halo work: 4.43 -> 4.79 ms.
@@ -166,6 +167,7 @@ struct rpe_handle {
     // matching
     int *d_m_q = nullptr, *d_m_t = nullptr, *d_m_d = nullptr, *d_m_n = nullptr;
     unsigned long long *d_m_best = nullptr;   // L2 matcher: [pair][kcap] packed (f32 dist bits << 18 | trainIdx) of the best elector
+    unsigned *d_hm_best = nullptr, *d_hm_row = nullptr;   // Hamming matcher, small batches (<= RPE_MATCH_SPLIT_PAIRS pairs): election / own-nearest words in HBM
     unsigned long long *d_m_best2 = nullptr;  // L2 matcher: [pair][kcap] the same key of the query's own nearest train (second crossCheck pass)
     float2 *d_pts1 = nullptr, *d_pts2 = nullptr;   // [pair][max_matches]
     // RANSAC
@@ -185,6 +187,7 @@ struct rpe_handle {
     double *d_R = nullptr, *d_t = nullptr, *d_E = nullptr;
     int *d_inliers = nullptr, *d_status = nullptr;
     double K_last[9] = {0}; bool K_valid = false;        // camera matrix resident in d_K (re-uploaded only when it changes)
+    uint8_t *d_resall = nullptr; unsigned *d_ovfall = nullptr;   // whole-batch result block / flag words of a chunked host batch (created on first use)
     uint8_t *d_resblk = nullptr, *h_resblk = nullptr;   // d_R, d_t, d_inliers, d_status, d_m_n live in d_resblk; pinned host mirror
     double *d_K = nullptr;
     // profiling
