@@ -204,6 +204,41 @@ static int poly_real_roots(const double *c, int n, double *roots)
     return nr_prev;
 }
 
+/* cv::solvePoly (core/mathfuncs.cpp; Durand-Kerner / Weierstrass sweeps in complex f64, Gauss-Seidel style, 300 sweeps unless the
+ * largest correction becomes exactly 0) restated -- experiment knob 3 = 1: cv2's findEssentialMat keeps the roots with
+ * |imag| <= 1e-10 in solvePoly's OUTPUT order (the order decides between models of one sample with equal inlier counts, and
+ * the imaginary-part filter decides which ill-conditioned real roots exist at all).  Start values 1, (1+i), (1+i)^2, ... */
+int orc_debug_get_variant(int key);
+static int solve_poly_dk(const double *c, int n, double *re, double *im)
+{
+    double rr[10], ri[10];
+    double pr = 1., pi = 0.;
+    for (int i = 0; i < n; ++i) { rr[i] = pr; ri[i] = pi; const double t = pr * 1. - pi * 1.; pi = pr * 1. + pi * 1.; pr = t; }
+    for (int iter = 0; iter < 300; ++iter) {
+        double maxdiff = 0.;
+        for (int i = 0; i < n; ++i) {
+            const double xr = rr[i], xi = ri[i];
+            double nr = c[n], ni = 0., dr = c[n], di = 0.;
+            for (int j = 0; j < n; ++j) {
+                double tr = nr * xr - ni * xi, ti = nr * xi + ni * xr;         /* num = num * p + coeffs[n-j-1] */
+                nr = tr + c[n - j - 1]; ni = ti;
+                if (j != i) {
+                    const double er = xr - rr[j], ei = xi - ri[j];
+                    if (er != 0. || ei != 0.) { tr = dr * er - di * ei; ti = dr * ei + di * er; dr = tr; di = ti; }
+                }
+            }
+            const double t = 1. / (dr * dr + di * di);                          /* num /= denom */
+            const double qr = (nr * dr + ni * di) * t, qi = (-nr * di + ni * dr) * t;
+            rr[i] = xr - qr; ri[i] = xi - qi;
+            const double ad = sqrt(qr * qr + qi * qi);
+            if (ad > maxdiff) maxdiff = ad;
+        }
+        if (maxdiff <= 0.) break;
+    }
+    for (int i = 0; i < n; ++i) { re[i] = rr[i]; im[i] = fabs(ri[i]) < 1e-100 ? 0. : ri[i]; }
+    return n;
+}
+
 /* --------------------------------------------------- five-point solver */
 /* Restates EMEstimatorCallback::runKernel (five-point.cpp): null space of the
  * 5x9 epipolar system, 10 cubic constraints (det E = 0, 2EE'E - tr(EE')E = 0),
@@ -327,7 +362,14 @@ int orc_five_point(const double *x1, const double *x2, double *E_out)
     int n = 10;
     for (; n > 1; --n) if (fabs(c10[n]) > DBL_EPSILON) break;
     double roots[10];
-    int nroots = poly_real_roots(c10, n, roots);
+    int nroots;
+    if (orc_debug_get_variant(3) == 1) {
+        double re[10], im[10];
+        solve_poly_dk(c10, n, re, im);
+        nroots = 0;
+        for (int i = 0; i < n; ++i) if (!(fabs(im[i]) > 1e-10)) roots[nroots++] = re[i];
+    } else
+        nroots = poly_real_roots(c10, n, roots);
     int count = 0;
     for (int ri = 0; ri < nroots && count < 10; ++ri) {
         double z = roots[ri];

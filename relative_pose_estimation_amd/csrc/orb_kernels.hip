@@ -4,15 +4,17 @@
 // .detectAndCompute(image, None)  (reference src/core/pose_estimator.py:85-91,:108).
 // Kernels (all images of the batch per launch; the stage names are the hipEvent slots of rpe_get_stage_ms):
 //   pyramid  : pyr_resize x11: INTER_LINEAR_EXACT chain, 8.8 fixed point, 128x64 tiles, source window in LDS
-//   fast     : fast_nms: FAST-9/16 score + 3x3 NMS + 31-px border filter + per-level score histogram, fused;
+//   fast     : fast_nms: FAST-9/16 score + 3x3 NMS + 31-px border filter, fused, per-tile keypoint lists;
 //              tiles cover the border-filtered region only ("nms" slot is empty)
-//   select   : select_candidates: retainBest(2*quota) threshold from the histogram, raster-ordered compaction
+//   select   : raster_corners (a level's tile lists -> one list in FAST's raster emission order) + retain_fast:
+//              retainBest(2*quota) on the FAST score, replayed as the C++ runtime's nth_element + partition (cv2's ORDER)
 //   harris   : 7x7 Harris response per candidate (f32, op order = oracle)
-//   keypoints: select_keypoints: retainBest(quota), one wave per level, raster-ordered compaction, level-major
+//   keypoints: retain_harris: retainBest(quota) on the Harris response, same replay; compact_keypoints: level-major lists
 //   angle    : orient_describe: one wave per keypoint: patch in LDS -> intensity-centroid angle (fastAtan2) ->
-//              Gaussian 7x7 on the patch -> 256-bit steered BRIEF ("blur" / "describe" slots are empty; the
+//              Gaussian 7x7 on the patch (cv2's sepFilter2D f32 route, fused multiply-adds) -> 256-bit steered BRIEF ("blur" / "describe" slots are empty; the
 //              whole-level blur kernel below only serves rpe_orb_debug_fetch)
-// Everything is integer or mirrored-order f32, so results equal the CPU oracle bit for bit.
+// Everything is integer or mirrored-order f32, so results equal the CPU oracle bit for bit -- and, on the reference's own
+// image pairs, cv2's (tests/test_reference_rows_cpu.py, tests/test_gpu_round3.py).
 #include "rpe_internal.h"
 #include "rpe_devmath.h"
 #include "retain_best_emul.h"
@@ -237,7 +239,7 @@ void rpe_launch_pyramid(rpe_handle *h, int n_img)
 }
 
 // ------------------------------------------------------------- FAST + NMS
-// Fused FAST-9/16 score + 3x3 non-maximum suppression + border filter + histogram.
+// Fused FAST-9/16 score + 3x3 non-maximum suppression + border filter.
 // Tile = 64x64 output pixels; scores are needed on 66x66, pixels on 72x72 (halo 3+1
 // rows, 4 columns => dword aligned).  ~5 KB of loads in flight per workgroup.
 //  phase 1: every dword group (4 px) of the 66x72 score area: OpenCV's pair test on the
@@ -248,7 +250,7 @@ void rpe_launch_pyramid(rpe_handle *h, int n_img)
 //  phase 2: list processed densely: 16 ring differences, window-9 min/max via
 //           min3/max3, score = max(A,B)-1 (0 if not a corner) into the LDS score tile.
 //  phase 3: strict 3x3 maximum on the LDS score tile, 31-px border filter
-//           (KeyPointsFilter::runByImageBorder), 256-bin histogram, per-tile keypoint list to HBM.
+//           (KeyPointsFilter::runByImageBorder), per-tile keypoint list to HBM.
 __device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
 __device__ __forceinline__ int imax3(int a, int b, int c) { return max(a, max(b, c)); }
 typedef short short2_t __attribute__((ext_vector_type(2)));
@@ -262,22 +264,21 @@ static constexpr int CIRC_DY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0
 #define FAST_NRP (FAST_THREADS / 18)  // rows of the 18-dword tile row that one pass of the lanes covers (14 or 7)
 #define FAST_LANES (FAST_NRP * 18)
 // Output: one compact list per tile of the keypoints that survive NMS and the border filter, packed
-// score << 24 | y << 12 | x (level coordinates), plus the per-(image, level) score histogram.  A strict 3x3
+// score << 24 | y << 12 | x (level coordinates).  A strict 3x3
 // maximum cannot have an 8-neighbour that is one too, so a 64x64 tile holds at most 32*32 = 1024 of them:
 // RPE_FAST_TILE_CAP is never exceeded and nothing is ever dropped here.  ~0.5 % of the pixels survive, so
 // the lists replace a dense NMS map (1.6 MB written + re-read per VGA image) by ~100 bytes per tile; list
 // order inside a tile depends on wave timing, which nothing downstream reads (select ranks by (y, x)).
 __global__ __launch_bounds__(FAST_THREADS) void fast_nms_kernel(const uint8_t *__restrict__ pyr, unsigned *__restrict__ tile_list,
-                                                        int *__restrict__ tile_cnt, unsigned *__restrict__ hist, RpeDeviceLayout lay,
+                                                        int *__restrict__ tile_cnt, RpeDeviceLayout lay,
                                                         const RpeTile *__restrict__ tiles, int ntiles)
 {
     // 19.5 KB of LDS per workgroup = 8 workgroups (32 waves) per CU: the pixel tile is dead after phase 2, so the keypoint
-    // list and the histogram of phase 3 live in its place (4096 + 1024 <= 5184 bytes); at 24.5 KB only 6 workgroups fit
+    // list of phase 3 lives in its place (4096 <= 5184 bytes); at 24.5 KB only 6 workgroups fit
     constexpr int S_IN_DW = FAST_PROWS * 18 > RPE_FAST_TILE_CAP + 256 ? FAST_PROWS * 18 : RPE_FAST_TILE_CAP + 256;
     __shared__ __attribute__((aligned(16))) unsigned s_in[S_IN_DW];                // pixels  y0-4 .. y0+FAST_TH+3, x0-4 .. x0+67 (sized for the phase-3 aliases too)
     __shared__ __attribute__((aligned(16))) unsigned s_sc[FS_ROWS * 18];   // scores  y0-1 .. y0+64, x0-4 .. x0+67
     unsigned *s_out = s_in;                                               // phase 3: the tile's keypoint list [1024]
-    unsigned *s_hist = s_in + RPE_FAST_TILE_CAP;                          // phase 3: score histogram [256]
     __shared__ unsigned short s_cand[FS_ROWS * 72];
     __shared__ int s_ncand, s_nout;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -429,11 +430,9 @@ __global__ __launch_bounds__(FAST_THREADS) void fast_nms_kernel(const uint8_t *_
         if (s > thr) ((uint8_t *)s_sc)[ry * 72 + bx] = (uint8_t)(s - 1);
     }
     __syncthreads();
-    // ---- phase 3: NMS + border filter + histogram over the candidate list (only pixels that went through
+    // ---- phase 3: NMS + border filter over the candidate list (only pixels that went through
     // phase 2 can hold a score); survivors are appended to the tile's list, one LDS atomic per wave and round.
-    // The pixel tile is dead now (the barrier above ended phase 2): its LDS holds the list and the histogram.
-    for (int i = tid; i < 256; i += FAST_THREADS) s_hist[i] = 0;
-    __syncthreads();
+    // The pixel tile is dead now (the barrier above ended phase 2): its LDS holds the list.
     const uint8_t *sc = (const uint8_t *)s_sc;
     for (int i0 = 0; i0 < ncand; i0 += FAST_THREADS) {                  // block-uniform trip count: the ballot sees whole waves
         const int i = i0 + tid;
@@ -454,7 +453,6 @@ __global__ __launch_bounds__(FAST_THREADS) void fast_nms_kernel(const uint8_t *_
             if (inside & (v != 0) & (v > nmax)) {
                 keep = true;
                 ent = ((unsigned)v << 24) | ((unsigned)py << 12) | (unsigned)px;
-                atomicAdd(&s_hist[v], 1u);
             }
         }
         const unsigned long long km = __ballot(keep);
@@ -470,19 +468,14 @@ __global__ __launch_bounds__(FAST_THREADS) void fast_nms_kernel(const uint8_t *_
     unsigned *dst = tile_list + tslot * RPE_FAST_TILE_CAP;
     for (int i = tid; i < nout; i += FAST_THREADS) dst[i] = s_out[i];
     if (tid == 0) tile_cnt[tslot] = nout;
-    for (int i = tid; i < 256; i += FAST_THREADS) {
-        const unsigned hc = s_hist[i];
-        if (hc) atomicAdd(&hist[((long long)blockIdx.y * RPE_NLEVELS + t.level) * 256 + i], hc);
-    }
 }
 
 void rpe_launch_fast(rpe_handle *h, int n_img)
 {
-    hipMemsetAsync(h->d_hist, 0, sizeof(unsigned) * 256 * RPE_NLEVELS * (size_t)n_img, h->stream);
     // tiles cover the border-filtered region only
     if (h->n_tiles_fast == 0) return;
     hipLaunchKernelGGL(fast_nms_kernel, dim3((h->n_tiles_fast + 7) / 8 * 8, n_img), dim3(FAST_THREADS), 0, h->stream,
-                       h->d_pyr, h->d_tile_list, h->d_tile_cnt, h->d_hist, h->lay, h->d_tiles_fast, h->n_tiles_fast);
+                       h->d_pyr, h->d_tile_list, h->d_tile_cnt, h->lay, h->d_tiles_fast, h->n_tiles_fast);
 }
 
 void rpe_launch_nms(rpe_handle *h, int n_img) { (void)h; (void)n_img; }   // fused into fast_nms_kernel
