@@ -691,7 +691,7 @@ void rpe_launch_select(rpe_handle *h, int n_img)
                        (const unsigned *)h->d_corner, (const int *)h->d_corner_count, h->d_cand_xy, h->d_cand_count, h->d_ovf, h->lay,
                        0, std::min(ccap_max, RPE_RETAIN_TIER), n_img);
     if (nlev_big > 0)
-        hipLaunchKernelGGL(retain_fast_kernel, dim3(nlev_big, std::min(n_img, 256)), dim3(64), lds_of(ccap_max), h->stream,
+        hipLaunchKernelGGL(retain_fast_kernel, dim3(nlev_big, std::min(n_img, 512)), dim3(64), lds_of(ccap_max), h->stream,
                            (const unsigned *)h->d_corner, (const int *)h->d_corner_count, h->d_cand_xy, h->d_cand_count, h->d_ovf, h->lay,
                            RPE_RETAIN_TIER, ccap_max, n_img);
 }

@@ -90,6 +90,19 @@ class Rendezvous:
             raise CommUnavailable(f"rendezvous directory {root} is not private to this user")
         self.dir = os.path.join(root, job)
         os.makedirs(self.dir, mode=0o700, exist_ok=True)
+        # files of an EARLIER launch under the same tag (an explicit RPE_COMM_TAG reused, a crashed run) must not be read as
+        # this launch's: nothing older than STALE_S before this process came up is accepted, and rank 0 sweeps such files away.
+        # (Reusing an explicit tag within STALE_S of a crashed launch is the one case this cannot tell apart: use a fresh tag.)
+        self.t_min = time.time() - self.STALE_S
+        if self.rank == 0:
+            for f in os.listdir(self.dir):
+                try:
+                    if os.stat(os.path.join(self.dir, f)).st_mtime < self.t_min:
+                        os.remove(os.path.join(self.dir, f))
+                except OSError:
+                    pass
+
+    STALE_S = 120.0
 
     def publish(self, name, payload=b""):
         final = os.path.join(self.dir, name)
@@ -107,7 +120,8 @@ class Rendezvous:
         while True:
             try:
                 with open(path, "rb") as fh:
-                    return fh.read()
+                    if os.fstat(fh.fileno()).st_mtime >= self.t_min:
+                        return fh.read()
             except FileNotFoundError:
                 pass
             if time.time() - t0 > self.timeout:

@@ -121,7 +121,7 @@ print("|".join(out), flush=True)
 """
 
 
-def _run_ranks(tmp_path, style, extra_env=None, world=2):
+def _run_ranks(tmp_path, style, extra_env=None, world=2, tag="42"):
     """style 'torchrun': python -m torch.distributed.run starts the ranks (RANK / WORLD_SIZE / MASTER_* / TORCHELASTIC_RUN_ID
     from the launcher); style 'plain': one subprocess per rank with RANK / WORLD_SIZE and an explicit RPE_COMM_TAG, as under
     mpirun / srun / a wrapper shell (different parents: nothing may depend on the parent pid)."""
@@ -141,7 +141,7 @@ def _run_ranks(tmp_path, style, extra_env=None, world=2):
         return outs
     procs = []
     for r in range(world):
-        e = dict(env, RANK=str(r), WORLD_SIZE=str(world), RPE_COMM_TAG="job42")
+        e = dict(env, RANK=str(r), WORLD_SIZE=str(world), RPE_COMM_TAG="job" + tag)
         e.pop("TORCHELASTIC_RUN_ID", None)
         # every rank behind its own wrapper shell: the ranks do NOT share a parent process
         procs.append(subprocess.Popen(["/bin/sh", "-c", f"exec {sys.executable} {script}"] if r % 2 else [sys.executable, str(script)],
@@ -160,9 +160,9 @@ def test_rendezvous_two_ranks_both_launch_styles(tmp_path):
 
 def test_rendezvous_failures_are_agreed(tmp_path):
     """a failure on ONE rank is CommUnavailable on ALL ranks -- nobody is left polling or waiting in a collective"""
-    outs = _run_ranks(tmp_path, "plain", {"RPE_TEST_FAIL_ID": "1"})
+    outs = _run_ranks(tmp_path, "plain", {"RPE_TEST_FAIL_ID": "1"}, tag="43")
     assert all(o.startswith("unavailable:") and "stub: no librccl" in o for o in outs), outs
-    outs = _run_ranks(tmp_path, "plain", {"RPE_TEST_FAIL_PREPARE": "1"})
+    outs = _run_ranks(tmp_path, "plain", {"RPE_TEST_FAIL_PREPARE": "1"}, tag="44")        # a fresh tag per launch (Rendezvous docstring)
     assert all("|unavailable:prepare: rank 1: hipMalloc failed" in o for o in outs), outs
 
 
