@@ -10,17 +10,16 @@
  * (runByImageBorder, retainBest), imgproc resize.cpp (INTER_LINEAR_EXACT,
  * ufixedpoint16) and smooth (fixed-point Gaussian), mathfuncs_core (fastAtan2).
  *
- * Own conventions where OpenCV's result is implementation-defined or cannot be
- * reproduced offline (all "parity unpinned" vs cv2, DESIGN.md lists them):
- *  - keypoint ORDER: level-major, raster (y, x) inside a level.  OpenCV's order
- *    after retainBest is std::nth_element-defined; the kept SET is identical
- *    (all keypoints with response >= the n-th best response).
- *  - the 256-pair rBRIEF pattern (bit_pattern_31_) is written from memory;
- *  - Gaussian 7x7 sigma=2 fixed-point kernel [18,34,48,56,48,34,18]/256;
- *  - cos/sin of the keypoint angle use a deterministic f64 kernel (fdlibm
- *    polynomials) so that the HIP kernel reproduces the same f32 values.
- *  - fixed workspace caps (candidates per level 4*quota+256; keypoints per
- *    image `cap`), truncating in canonical order.
+ * Conventions: the defaults of the knobs below are the ones the reference's own 147 result rows pin
+ * (tests/test_reference_rows_cpu.py):
+ *  - keypoint ORDER inside a level: what cv2's two retainBest calls leave behind, i.e. the C++ runtime's
+ *    std::nth_element + std::partition (retain_best.cpp: the real libstdc++ ones; MSVC's and libc++'s restated);
+ *  - descriptor blur: sepFilter2D's f32 route with fused multiply-adds (GaussianBlur on a pyramid sub-matrix);
+ *  - the 256-pair rBRIEF pattern (bit_pattern_31_), written from memory and confirmed by the rows;
+ *  - cos/sin of the keypoint angle from a deterministic f64 kernel (fdlibm polynomials), so that the HIP kernel
+ *    reproduces the same f32 values (own convention, invisible in the rows);
+ *  - fixed workspace caps (raster corner list per level clamp(w h / 64, 1024, 8192); candidates 4*quota+256;
+ *    keypoints per image `cap`), truncating in cv2's own order and flagged (cv2 has no caps).
  */
 #include "oracle.h"
 #include <math.h>

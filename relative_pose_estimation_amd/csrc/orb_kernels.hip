@@ -972,23 +972,34 @@ __global__ __launch_bounds__(64 * KP_PER_WG) void orient_describe_kernel(const u
                     const unsigned d0 = pw[0], d1 = pw[1], d2 = pw[2], d3 = pw[3], d4 = pw[4];
                     const unsigned q0 = __builtin_amdgcn_alignbyte(d1, d0, off0), q1 = __builtin_amdgcn_alignbyte(d2, d1, off0),
                                    q2 = __builtin_amdgcn_alignbyte(d3, d2, off0), q3 = __builtin_amdgcn_alignbyte(d4, d3, off0);
-                    float f[16];
+                    // two outputs per v_pk_mul_f32 / v_pk_fma_f32 (each half an IEEE fma of its own: same bits as the scalar
+                    // form).  A packed operand is an aligned register pair, so the converted pixels are kept twice: pairs
+                    // starting at even bytes (fe) and at odd bytes (fo); output pair (o, o + 1), tap k reads pair o + k.
+                    typedef float v2f_t __attribute__((ext_vector_type(2)));
+                    const unsigned qq[4] = {q0, q1, q2, q3};
+                    v2f_t fe[8], fo[7];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        f[e] = (float)((q0 >> (8 * e)) & 255u); f[4 + e] = (float)((q1 >> (8 * e)) & 255u);
-                        f[8 + e] = (float)((q2 >> (8 * e)) & 255u); f[12 + e] = (float)((q3 >> (8 * e)) & 255u);
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned w = qq[e >> 1] >> (16 * (e & 1));
+                        fe[e] = (v2f_t){(float)(w & 255u), (float)((w >> 8) & 255u)};
                     }
-                    float *dst = hb + (8 * cg) * KP_HSTRIDE + row;
 #pragma unroll
-                    for (int o = 0; o < 8; ++o) {
-                        float sacc = g0 * f[o];
-                        sacc = __builtin_fmaf(g1, f[o + 1], sacc);
-                        sacc = __builtin_fmaf(g2, f[o + 2], sacc);
-                        sacc = __builtin_fmaf(g3, f[o + 3], sacc);
-                        sacc = __builtin_fmaf(g2, f[o + 4], sacc);      // the kernel is symmetric: g4 = g2, g5 = g1, g6 = g0 (same f32 values)
-                        sacc = __builtin_fmaf(g1, f[o + 5], sacc);
-                        sacc = __builtin_fmaf(g0, f[o + 6], sacc);
-                        dst[o * KP_HSTRIDE] = sacc;
+                    for (int e = 0; e < 7; ++e) fo[e] = (v2f_t){fe[e].y, fe[e + 1].x};
+                    float *dst = hb + (8 * cg) * KP_HSTRIDE + row;
+                    const v2f_t G0 = {g0, g0}, G1 = {g1, g1}, G2 = {g2, g2}, G3 = {g3, g3};
+#pragma unroll
+                    for (int o = 0; o < 8; o += 2) {
+                        // pair j = o + k: even j -> fe[j / 2], odd j -> fo[(j - 1) / 2]
+                        auto P = [&](int j) -> v2f_t { return (j & 1) ? fo[(j - 1) >> 1] : fe[j >> 1]; };
+                        v2f_t sacc = G0 * P(o);
+                        sacc = __builtin_elementwise_fma(G1, P(o + 1), sacc);
+                        sacc = __builtin_elementwise_fma(G2, P(o + 2), sacc);
+                        sacc = __builtin_elementwise_fma(G3, P(o + 3), sacc);
+                        sacc = __builtin_elementwise_fma(G2, P(o + 4), sacc);      // the kernel is symmetric: g4 = g2, g5 = g1, g6 = g0 (same f32 values)
+                        sacc = __builtin_elementwise_fma(G1, P(o + 5), sacc);
+                        sacc = __builtin_elementwise_fma(G0, P(o + 6), sacc);
+                        dst[o * KP_HSTRIDE] = sacc.x;
+                        dst[(o + 1) * KP_HSTRIDE] = sacc.y;
                     }
                 }
             }
