@@ -145,17 +145,24 @@ static void sift_geometry(int W, int H, sift_geo *g)
 
 static int refl(int p, int n) { if (n == 1) return 0; while (p < 0 || p >= n) { if (p < 0) p = -p; if (p >= n) p = 2 * n - 2 - p; } return p; }
 
+/* GaussianBlur on an f32 image = sepFilter2D with the f32 Gaussian kernel (imgproc filter.simd.hpp), in the operation order
+ * of the AVX2-dispatched build every x86 wheel runs (the reference's own ORB rows single out the fused form of this very
+ * code for the descriptor blur, orb_oracle.c):
+ *   row pass     RowVec_32f:        s = k[0] v[x-r];  s = fma(k[i], v[x-r+i], s), i = 1 .. ks-1
+ *   column pass  SymmColumnVec_32f: s = k[r] c;       s = fma(k[r+j], v[y+j] + v[y-j], s), j = 1 .. r
+ * (rounds 1-2 summed all taps of both passes unfused and in ascending order.)  SIFT itself stays parity unpinned against
+ * cv2 -- the reference holds no SIFT answers. */
 static void blur_f32(const float *src, float *dst, float *tmp, int w, int h, const float *k, int ks)
 {
     int r = ks / 2;
     for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
-        float s = 0.f;
-        for (int i = 0; i < ks; ++i) s += k[i] * src[(size_t)y * w + refl(x + i - r, w)];
+        float s = k[0] * src[(size_t)y * w + refl(x - r, w)];
+        for (int i = 1; i < ks; ++i) s = fmaf(k[i], src[(size_t)y * w + refl(x + i - r, w)], s);
         tmp[(size_t)y * w + x] = s;
     }
     for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
-        float s = 0.f;
-        for (int i = 0; i < ks; ++i) s += k[i] * tmp[(size_t)refl(y + i - r, h) * w + x];
+        float s = k[r] * tmp[(size_t)y * w + x];
+        for (int j = 1; j <= r; ++j) s = fmaf(k[r + j], tmp[(size_t)refl(y + j, h) * w + x] + tmp[(size_t)refl(y - j, h) * w + x], s);
         dst[(size_t)y * w + x] = s;
     }
 }

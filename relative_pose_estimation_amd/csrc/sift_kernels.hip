@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) void sift_blur_row_kernel(const float *__restr
     __syncthreads();
     const int x = x0 + threadIdx.x;
     if (x >= w) return;
-    float acc = 0.f;
-    for (int i = 0; i < ks; ++i) acc += c_skern[kid][i] * seg[threadIdx.x + i];
+    float acc = c_skern[kid][0] * seg[threadIdx.x];                      // cv2's RowVec_32f order: first product, then fused taps
+    for (int i = 1; i < ks; ++i) acc = __builtin_fmaf(c_skern[kid][i], seg[threadIdx.x + i], acc);
     dst[(long long)blockIdx.z * dstride + (size_t)y * w + x] = acc;
 }
 
@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) void sift_blur_col_kernel(const float *__restr
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     const float *s = src + (long long)blockIdx.z * sstride;
-    float acc = 0.f;
-    for (int i = 0; i < ks; ++i) acc += c_skern[kid][i] * s[(size_t)s_refl(y + i - r, h) * w + x];
+    float acc = c_skern[kid][r] * s[(size_t)y * w + x];                  // cv2's SymmColumnVec_32f order: centre, then fused symmetric pairs
+    for (int j = 1; j <= r; ++j) acc = __builtin_fmaf(c_skern[kid][r + j], s[(size_t)s_refl(y + j, h) * w + x] + s[(size_t)s_refl(y - j, h) * w + x], acc);
     dst[(long long)blockIdx.z * dstride + (size_t)y * w + x] = acc;
 }
 
@@ -154,8 +154,10 @@ __global__ __launch_bounds__(256) void sift_blur_col_kernel(const float *__restr
 // row pass runs on all TH+2R window rows into a second LDS plane, the column pass reads that plane
 // and writes G[i]: the level is read once and written once (the unfused version went through HBM
 // between the passes).  Each lane accumulates 8 outputs from a register window of 8+2R values; tap
-// order and accumulation order are the oracle's (acc = 0; acc += k[i]*v[i], i ascending), so the
-// f32 results are bit-identical.
+// order and accumulation order are cv2's sepFilter2D f32 route on its AVX2 build, as the oracle restates it
+// (row: first product, then fma(k[i], v[i], acc), i ascending; column: centre, then fma(k[r+j], v[+j] + v[-j], acc)),
+// so the f32 results are bit-identical.  (Rounds 1-2 summed every tap of both passes unfused: twice the
+// vector instructions of this issue-limited kernel.)
 __device__ __forceinline__ void asm_pin(float __attribute__((ext_vector_type(2))) &p) { asm volatile("" : "+v"(p)); }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // P[m] = (lds[addr + 4*m*S], lds[addr + 4*(m+4)*S]) for every m of the sequence, S = 1 (ds_read2_b32) or 64 dwords
@@ -317,8 +319,8 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
     for (int i = 0; i < KS; ++i) k[i] = c_skern[kid][i];
     __syncthreads();
     // Both passes: a lane produces 8 outputs as 4 packed pairs (j, j+4); the tap window is held as
-    // pairs P[m] = (v[m], v[m+4]) so that every multiply and add is a v_pk_*_f32 (two IEEE f32
-    // operations per instruction, same rounding as the scalar ones: no contraction).  The pairs come
+    // pairs P[m] = (v[m], v[m+4]) so that every multiply, add and fused multiply-add is a v_pk_*_f32 (two IEEE f32
+    // operations per instruction, same rounding as the scalar ones).  The pairs come
     // straight out of LDS: ds_read2_b32 / ds_read2st64_b32 take two independent offsets, so one
     // instruction returns (v[m], v[m+4]) in an aligned register pair (left to the compiler the loads
     // pair up as (v[m], v[m+1]) and 40 v_mov per item rebuild the operands: 16 % of the kernel).
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
         for (int j = 0; j < 4; ++j) {
             f32x2 acc = f32x2{k[0], k[0]} * P[j];
 #pragma unroll
-            for (int i = 1; i < KS; ++i) { const f32x2 kk = {k[i], k[i]}; acc += kk * P[j + i]; }
+            for (int i = 1; i < KS; ++i) { const f32x2 kk = {k[i], k[i]}; acc = __builtin_elementwise_fma(kk, P[j + i], acc); }      // RowVec_32f: one v_pk_fma_f32 per tap pair
             oj[j][0] = acc.x;
             oj[j][4] = acc.y;
         }
@@ -367,9 +369,10 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
         float *so = s_win + (8 * g) * 64;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            f32x2 acc = f32x2{k[0], k[0]} * P[j];
+            // SymmColumnVec_32f: centre tap, then one v_pk_add_f32 + one v_pk_fma_f32 per symmetric tap pair
+            f32x2 acc = f32x2{k[R], k[R]} * P[j + R];
 #pragma unroll
-            for (int i = 1; i < KS; ++i) { const f32x2 kk = {k[i], k[i]}; acc += kk * P[j + i]; }
+            for (int t = 1; t <= R; ++t) { const f32x2 kk = {k[R + t], k[R + t]}; acc = __builtin_elementwise_fma(kk, P[j + R + t] + P[j + R - t], acc); }
             if (whole) {
                 so[j * 64 + lane] = acc.x;
                 so[(j + 4) * 64 + lane] = acc.y;
