@@ -1302,10 +1302,21 @@ static void sift_blur_launch(rpe_handle *h, const float *src, long long sstride,
                              long long dogstride, int w, int hh, int kid, int n_img, const uint8_t *u8a = nullptr,
                              const uint8_t *u8b = nullptr, int na = 0, float *dec = nullptr, int w2 = 0, int h2 = 0)
 {
-    constexpr int TH = 32;
-    const int tcols = (w + 63) / 64, ntiles = tcols * ((hh + TH - 1) / TH);
-    hipLaunchKernelGGL((sift_blur_fused_kernel<R, TH, UPS>), dim3((ntiles + 7) / 8 * 8, n_img), dim3(256), 0, h->stream, src, sstride, dst, dstride,
-                       w, hh, kid, tcols, ntiles, u8a, u8b, na, w / 2, hh / 2, dec, w2, h2);
+    // tile height: 32 rows everywhere measured best while the kernel was issue-limited; RPE_SIFT_TH64=<min radius> (diagnostic)
+    // gives the radii from that one on 64-row tiles (less halo per output row, half the workgroups per CU)
+    static const int th64_from = getenv("RPE_SIFT_TH64") ? atoi(getenv("RPE_SIFT_TH64")) : 1000;
+    const int tcols = (w + 63) / 64;
+    if (R >= th64_from) {
+        constexpr int TH = 64;
+        const int ntiles = tcols * ((hh + TH - 1) / TH);
+        hipLaunchKernelGGL((sift_blur_fused_kernel<R, TH, UPS>), dim3((ntiles + 7) / 8 * 8, n_img), dim3(256), 0, h->stream, src, sstride, dst, dstride,
+                           w, hh, kid, tcols, ntiles, u8a, u8b, na, w / 2, hh / 2, dec, w2, h2);
+    } else {
+        constexpr int TH = 32;
+        const int ntiles = tcols * ((hh + TH - 1) / TH);
+        hipLaunchKernelGGL((sift_blur_fused_kernel<R, TH, UPS>), dim3((ntiles + 7) / 8 * 8, n_img), dim3(256), 0, h->stream, src, sstride, dst, dstride,
+                           w, hh, kid, tcols, ntiles, u8a, u8b, na, w / 2, hh / 2, dec, w2, h2);
+    }
     if (dog)      // DoG planes are not stored by the product path (layers are formed where they are consumed); kept for callers that ask
         hipLaunchKernelGGL(sift_sub_kernel, dim3((unsigned)(((long long)w * hh + 255) / 256), 1, n_img), dim3(256), 0, h->stream,
                            (const float *)dst, dstride, src, sstride, dog, dogstride, (long long)w * hh);
