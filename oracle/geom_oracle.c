@@ -366,7 +366,7 @@ int orc_five_point(const double *x1, const double *x2, double *E_out)
     for (; n > 1; --n) if (fabs(c10[n]) > DBL_EPSILON) break;
     double roots[10];
     int nroots;
-    if (orc_debug_get_variant(3) == 1) {
+    if (orc_debug_get_variant(3) & 1) {
         double re[10], im[10];
         solve_poly_dk(c10, n, re, im);
         nroots = 0;

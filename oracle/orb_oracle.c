@@ -233,14 +233,15 @@ float orc_fast_atan2(float y, float x)
     const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
     const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
     float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    const int fused = g_variant[3] & 2;                     /* experiment knob 3, bit 1: the polynomial with fused multiply-adds */
     if (ax >= ay) {
         c = ay / (ax + (float)DBL_EPSILON);
         c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+        a = fused ? fmaf(fmaf(fmaf(p7, c2, p5), c2, p3), c2, p1) * c : (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
     } else {
         c = ax / (ay + (float)DBL_EPSILON);
         c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+        a = 90.f - (fused ? fmaf(fmaf(fmaf(p7, c2, p5), c2, p3), c2, p1) * c : (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c);
     }
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
