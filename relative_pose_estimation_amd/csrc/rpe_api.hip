@@ -387,6 +387,7 @@ extern "C" void rpe_destroy(rpe_handle *h)
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     rpe_sift_destroy(h);
+    for (auto &g : h->graphs) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }
     void *ptrs[] = {h->d_tiles_full, h->d_tiles_fast, h->d_coef, h->d_pyr_tiles, h->d_pyr, h->d_bufA, h->d_tile_list, h->d_tile_cnt, h->d_stage1, h->d_stage2,
                     h->d_hist, h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_angle,
                     h->d_kp_pt, h->d_kp_cs, h->d_kp_count, h->d_desc, h->d_m_q, h->d_m_t, h->d_m_d, h->d_resblk, h->d_pts1, h->d_pts2,
@@ -568,7 +569,41 @@ extern "C" int rpe_enqueue_batch_device(rpe_handle *h, const uint8_t *d_imgs1, c
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int rc = set_K(h, K);
     if (rc) return rc;
-    return run_pairs(h, d_imgs1, d_imgs2, B, B, B, B);
+    // Small batches are launch-bound on the HOST (one pair: ~50 launches for 0.6 ms of GPU work): the sequence is captured
+    // once per (input buffers, B) and replayed as a hipGraph.  Everything in it is stream-ordered kernels and memsets whose
+    // arguments depend only on the handle, the two buffers and B; K travels outside (set_K above).  Not while profiling (the
+    // stage events are host-side records), not for SIFT (its launch sequence reads back counts), RPE_NO_GRAPH=1 turns it off.
+    static const bool no_graph = getenv("RPE_NO_GRAPH") != nullptr;
+    if (B > RPE_GRAPH_MAX_PAIRS || h->profiling || h->cfg.feature_method != RPE_FEATURE_ORB || no_graph)
+        return run_pairs(h, d_imgs1, d_imgs2, B, B, B, B);
+    for (auto &g : h->graphs)
+        if (g.a == d_imgs1 && g.b == d_imgs2 && g.B == B) {
+            h->last_pairs = B; h->last_img2_base = B; h->last_chunked = false;
+            h->lay.in_na = B; h->level0_slots = 2 * B;
+            const bool direct = h->lay.lv[0].pitch == h->cfg.width && (((uintptr_t)d_imgs1 | (uintptr_t)d_imgs2) & 15) == 0;
+            h->lay.in_a = direct ? d_imgs1 : nullptr; h->lay.in_b = direct ? d_imgs2 : nullptr;
+            HIPCHK(h, hipGraphLaunch(g.exec, h->stream));
+            return RPE_OK;
+        }
+    rpe_handle::GraphEntry e{d_imgs1, d_imgs2, B, nullptr, nullptr};
+    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        return run_pairs(h, d_imgs1, d_imgs2, B, B, B, B);
+    }
+    rc = run_pairs(h, d_imgs1, d_imgs2, B, B, B, B);
+    const hipError_t ce = hipStreamEndCapture(h->stream, &e.graph);
+    if (rc != RPE_OK || ce != hipSuccess || !e.graph || hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (e.graph) hipGraphDestroy(e.graph);
+        return rc != RPE_OK ? rc : run_pairs(h, d_imgs1, d_imgs2, B, B, B, B);       // capture unavailable: plain launches
+    }
+    if (h->graphs.size() >= 4) {                                                    // a handful of (buffers, B) combinations at most
+        hipGraphExecDestroy(h->graphs.front().exec); hipGraphDestroy(h->graphs.front().graph);
+        h->graphs.erase(h->graphs.begin());
+    }
+    h->graphs.push_back(e);
+    HIPCHK(h, hipGraphLaunch(e.exec, h->stream));
+    return RPE_OK;
 }
 
 // Consecutive-frame stream (reference batch_processor.py:71-109): F frames -> F-1

@@ -13,6 +13,7 @@
 #define RPE_RANSAC_CHUNK 64    // solver wave granularity: 64 RANSAC iterations per wave
 #define RPE_RANSAC_MAXCHUNK 512 // largest number of iterations evaluated per launch group (8 waves per pair)
 #define RPE_MAX_MODELS 10
+#define RPE_GRAPH_MAX_PAIRS 16    // batches up to this many pairs are replayed as a captured hipGraph
 #define RPE_MATCH_SPLIT_PAIRS 64   // batches up to this many pairs split a pair's Hamming matching over several workgroups
 #define RPE_RESULT_BYTES 108     // per pair: R 72 + t 24 + inliers 4 + status 4 + n_matches 4
 // FAST tile = 64 x FAST_TH output pixels, FAST_TH * 4 threads.  Unlike the resize kernel (latency bound: smaller tiles
@@ -132,6 +133,10 @@ struct rpe_handle {
     hipStream_t copy_stream = nullptr;          // uploads of a chunked host batch (rpe_estimate_batch), created on first use
     hipEvent_t ev_up[8] = {};                   // 'chunk c is resident' events
     bool last_chunked = false;                  // the last host batch ran in chunks: per-pair debug arrays hold its last chunk only
+    // hipGraphs of the whole launch sequence of small batches (rpe_enqueue_batch_device): the drop-in's estimate() is a batch
+    // of ONE pair, ~50 launches of a few microseconds each; replaying them as one graph removes the per-launch host cost
+    struct GraphEntry { const uint8_t *a, *b; int B; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
     std::vector<uint32_t> ovf_pairs;            // capacity flags of a chunked host batch, per pair (OR of the pair's two images), kept across its chunks
     RpeDeviceLayout lay{};
     int n_img_cap = 0;              // 2*max_batch
