@@ -509,7 +509,38 @@ def dropin_operating_points(data, device, workers):
     e.device_free(d)
     e.close()
     out["host_entry"]["note"] = "1024 VGA pairs = 629 MB per batch; PCIe Gen5 x16 ~ 63 GB/s = 10 ms = a ceiling of ~100 k pairs/s for this entry"
+    out["reference_rows"] = reference_rows_on_gpu(device)
     return out
+
+
+def reference_rows_on_gpu(device):
+    """BASELINE's accuracy half on the reference's OWN inputs: every committed result row of the reference (147 image pairs of its
+    three evaluation runs, tests/golden/reference_rows/: the frames, ground truth, camera matrices and the CSV's est_* columns)
+    through PoseEstimator.estimate_batch with the reference's parameters (ORB 4000, top-500; pipeline.py:94-101).  Reported per
+    run: rows whose forward Euler triple (batch_processor.py:82-101) agrees with the CSV within 1e-6 / 1e-3 / 0.01 / 0.1 / 0.5 deg,
+    and the median rotation error beside the reference's.  keypoint_order = the C++ runtime of the cv2 build that produced
+    the file.  Reads fixtures only; the oracle is not involved."""
+    from relative_pose_estimation_amd import PoseEstimator, geometry
+    from tests import reference_rows as rr
+    res = {}
+    for name, order in (("sim", "msvc"), ("salah", "libstdc++"), ("phone", "libstdc++")):
+        ds = rr.load(name)
+        B = len(ds["frames2"])
+        pe = PoseEstimator(ds["K"], nfeatures=4000, max_matches=500, max_batch=B, device=device, keypoint_order=order)
+        t0 = time.perf_counter()
+        R, t, inl, st = pe.estimate_batch(ds["img1"], ds["img2"])
+        dt = time.perf_counter() - t0
+        pe.close()
+        diff = rr.euler_agreement(ds, R, geometry)
+        err = rr.rotation_errors(ds, R, geometry)
+        ref = ds["ref_rotation_error"]
+        res[name] = {"pairs": B, "image": f"{ds['img1'].shape[2]}x{ds['img1'].shape[1]}", "keypoint_order": order, "status_ok": int((st == 0).sum()),
+                     "rows_agreeing_within_deg": {f"{e:g}": c for e, c in zip(rr.AGREE_EDGES, rr.agreement_counts(diff))},
+                     "median_rotation_error_deg": round(float(np.median(err)), 4), "reference_median_rotation_error_deg": round(float(np.median(ref)), 4),
+                     "flips_over_90_deg": int((err > 90).sum()), "reference_flips_over_90_deg": int((ref > 90).sum()),
+                     "first_call_s_incl_workspace": round(dt, 3)}
+    res["total_rows_within_1e-6_deg"] = sum(v["rows_agreeing_within_deg"]["1e-06"] for v in res.values() if isinstance(v, dict))
+    return res
 
 
 def self_launch(args):
