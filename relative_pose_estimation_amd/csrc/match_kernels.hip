@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void match_hamming_kernel(const uint8_t *__res
     const int tid = threadIdx.x, pair = blockIdx.x;
     const int img1 = pair, img2 = img2_base + pair;
     const int n1 = min(kp_count[img1], kcap), n2 = min(kp_count[img2], kcap);
-    for (int i = tid; i < n1; i += 256) { s_best[i] = 0xFFFFFFFFu; s_row[i] = 0xFFFFFFFEu; }
+    for (int i = tid; i < n1; i += 256) { s_best[i] = 0xFFFFFFFFu; if (!RATIO) s_row[i] = 0xFFFFFFFEu; }      // ratio mode: no s_row (and no LDS for it)
     if (tid == 0) s_valid = 0;
     const uint4 *d1 = (const uint4 *)(desc + (long long)img1 * kcap * 32);
     const uint4 *d2 = (const uint4 *)(desc + (long long)img2 * kcap * 32);
@@ -394,11 +394,11 @@ void rpe_launch_match(rpe_handle *h, int B)
 {
     const int kcap = h->lay.kcap;
     size_t lds = (size_t)QTILE * 32 + (size_t)kcap * 8;       // staging / sort keys + election words + own-nearest words
-    if (h->cfg.match_mode == RPE_MATCH_RATIO)
-        hipLaunchKernelGGL((match_hamming_kernel<true>), dim3(B), dim3(256), lds, h->stream,
+    if (h->cfg.match_mode == RPE_MATCH_RATIO)                 // the ratio mode has no own-nearest words: 4 bytes per keypoint (<= 64 KB at 8064)
+        hipLaunchKernelGGL((match_hamming_kernel<true>), dim3(B), dim3(256), (size_t)QTILE * 32 + (size_t)kcap * 4, h->stream,
                            h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches, h->cfg.match_ratio,
                            h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
-    else if (getenv("RPE_MATCH_VALU"))                    // diagnostic: the vector-ALU crossCheck kernel (A/B runs, parity tests)
+    else if (getenv("RPE_MATCH_VALU") && lds <= 65536)    // diagnostic: the vector-ALU crossCheck kernel (A/B runs, parity tests)
         hipLaunchKernelGGL((match_hamming_kernel<false>), dim3(B), dim3(256), lds, h->stream,
                            h->d_desc, h->d_kp_count, h->d_kp_pt, h->img2_base ? h->img2_base : B, kcap, h->cfg.max_matches, 0.0,
                            h->d_m_q, h->d_m_t, h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
@@ -408,8 +408,11 @@ void rpe_launch_match(rpe_handle *h, int B)
         while (sortP < kcap) sortP <<= 1;
         const size_t r0 = (std::max((size_t)(2 * 8 * 64 + 16) * 16 + (size_t)kcap * 2, (size_t)sortP * 4) + 15) / 16;
         const int rounds = ((kcap + 31) / 32 + 7) / 8;
+        // the fused kernel keeps 8 bytes of election words per keypoint in LDS: beyond 64 KB per workgroup (nfeatures > ~4900) the
+        // HBM-resident form serves every batch size (rpe_create sizes d_hm_* for the whole batch then)
+        const bool lds_fits = r0 * 16 + (size_t)kcap * 8 <= 65536;
         const int split = B <= RPE_MATCH_SPLIT_PAIRS ? std::min(rounds, std::max(1, 256 / B)) : 1;
-        if (split > 1) {
+        if (split > 1 || !lds_fits) {
             hipMemsetAsync(h->d_hm_best, 0xFF, sizeof(unsigned) * (size_t)B * kcap, h->stream);
             hipMemsetAsync(h->d_hm_row, 0xFE, sizeof(unsigned) * (size_t)B * kcap, h->stream);
             hipLaunchKernelGGL((match_hamming_mfma_kernel<true>), dim3(B, split), dim3(MM_NT), r0 * 16, h->stream,

@@ -316,7 +316,12 @@ static int alloc_workspace(rpe_handle *h)
     HIPCHK(h, hipHostMalloc((void **)&h->h_resblk, (size_t)B * RPE_RESULT_BYTES));
     DM(h, h->d_pts1, B * mm); DM(h, h->d_pts2, B * mm);
     if (h->cfg.norm_type == RPE_NORM_L2) { DM(h, h->d_m_best, B * L.kcap); DM(h, h->d_m_best2, B * L.kcap); }
-    else { const size_t bs = B < RPE_MATCH_SPLIT_PAIRS ? B : RPE_MATCH_SPLIT_PAIRS; DM(h, h->d_hm_best, bs * L.kcap); DM(h, h->d_hm_row, bs * L.kcap); }
+    else {
+        // small batches (and, when the fused matcher's LDS would not fit, all batches) keep the election words in HBM
+        const bool big = (size_t)L.kcap * 8 + 32768 > 65536;
+        const size_t bs = big || B < RPE_MATCH_SPLIT_PAIRS ? B : RPE_MATCH_SPLIT_PAIRS;
+        DM(h, h->d_hm_best, bs * L.kcap); DM(h, h->d_hm_row, bs * L.kcap);
+    }
     DM(h, h->d_n1, B * mm); DM(h, h->d_n2, B * mm);
     DM(h, h->d_rstate, B); DM(h, h->d_found, B);
     DM(h, h->d_models, B * RPE_RANSAC_MAXCHUNK * RPE_MAX_MODELS * 9);

@@ -145,3 +145,20 @@ def test_retain_best_replay_on_long_and_truncated_lists(oracle, K_vga, order):
         e.close()
     finally:
         oracle.set_stl("libstdc++")
+
+
+def test_largest_keypoint_capacity(oracle, K_vga):
+    """nfeatures = 8000 (the largest the handle accepts): 8064 keypoints per image -- the Hamming matcher's election words no
+    longer fit the fused kernel's LDS and live in HBM for every batch size; the selection replays run their long-list
+    launches; GPU == oracle end to end, crossCheck and Lowe ratio."""
+    from relative_pose_estimation_amd import PoseEstimator, synthetic
+    i1, i2, _, _ = synthetic.make_batch(2, K_vga, cfg=6)
+    for ratio in (None, 0.8):
+        pe = PoseEstimator(K_vga, nfeatures=8000, max_matches=500, max_batch=2, ratio=ratio)
+        R, t, inl, st = pe.estimate_batch(i1, i2)
+        nm = pe._last_n_matches.copy()
+        pe.close()
+        for n in range(2):
+            r = oracle.estimate_pose(i1[n], i2[n], K_vga, 8000, 500, ratio=ratio)
+            assert st[n] == r["status"] == 0 and nm[n] == r["n_matches"] and inl[n] == r["inliers"], (ratio, n, nm[n], r["n_matches"])
+            assert np.array_equal(R[n], r["R"]) and np.array_equal(t[n], r["t"])
