@@ -683,6 +683,8 @@ void rpe_launch_select(rpe_handle *h, int n_img)
     }
     const int key_cap = ccap_max + wmax / 2 + 64;
     const size_t lds = sizeof(unsigned) * ((size_t)rows_cap + 1 + rows_cap + key_cap + nt_max + 1);
+    // images beyond ~3000 px need more than the default 64 KB of dynamic LDS per workgroup (gfx950 has 160 KB per CU)
+    if (lds > 65536) hipFuncSetAttribute((const void *)raster_corners_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(raster_corners_kernel, dim3(RPE_NLEVELS, n_img), dim3(256), lds, h->stream,
                        (const unsigned *)h->d_tile_list, (const int *)h->d_tile_cnt,
                        h->d_corner, h->d_corner_count, h->d_ovf, h->lay, h->n_tiles_fast, rows_cap, key_cap);

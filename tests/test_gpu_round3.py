@@ -162,3 +162,20 @@ def test_largest_keypoint_capacity(oracle, K_vga):
             r = oracle.estimate_pose(i1[n], i2[n], K_vga, 8000, 500, ratio=ratio)
             assert st[n] == r["status"] == 0 and nm[n] == r["n_matches"] and inl[n] == r["inliers"], (ratio, n, nm[n], r["n_matches"])
             assert np.array_equal(R[n], r["R"]) and np.array_equal(t[n], r["t"])
+
+
+def test_orb_on_a_3840x2160_image(oracle):
+    """A UHD frame (a reference HD frame doubled): the raster corner kernel needs 66 KB of dynamic LDS per workgroup here, more
+    than the 64 KB default -- keypoints in cv2's order, descriptors and flags still equal the oracle's."""
+    from relative_pose_estimation_amd import _capi
+    ds = rr.load("salah", rows=[3])
+    big = np.ascontiguousarray(np.kron(ds["img1"][0], np.ones((2, 2), np.uint8)))
+    assert big.shape == (2160, 3840)
+    e = _capi.Engine(3840, 2160, max_batch=1, nfeatures=4000, max_matches=500)
+    kps, desc, cnt = e.orb_detect_and_compute(big[None])
+    e.close()
+    ko, do, fo = oracle.orb_detect_and_compute(big, 4000, return_flags=True)
+    assert cnt[0] == len(ko) > 3000
+    kg = kps[0, :cnt[0]]
+    assert np.array_equal(kg["lx"], ko["lx"]) and np.array_equal(kg["ly"], ko["ly"]) and np.array_equal(kg["octave"], ko["octave"])
+    assert np.array_equal(kg["angle"].view(np.uint32), ko["angle"].view(np.uint32)) and np.array_equal(desc[0, :cnt[0]], do)
