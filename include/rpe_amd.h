@@ -61,7 +61,7 @@ enum {
     RPE_OVF_SIFT_RAW       = 1 << 5,   /* more oriented keypoints than the raw list holds */
     RPE_OVF_SIFT_PREFILTER = 1 << 6,   /* response ties overflowed the pre-sort window */
     RPE_OVF_SIFT_CAP       = 1 << 7,   /* the nfeatures cap removed keypoints: differs from the reference's uncapped SIFT_create() (pose_estimator.py:93-94) */
-    RPE_OVF_SIFT_KEYPOINTS = 1 << 8    /* more than nfeatures+64 keypoints after retainBest (ties) */
+    RPE_OVF_SIFT_KEYPOINTS = 1 << 8    /* more than nfeatures+64 keypoints after retainBest (ties), or more than RPE_SIFT_UNCAPPED_CAPACITY+64 without a cap */
 };
 
 /* library error codes (function return values) */
@@ -73,6 +73,7 @@ enum {
 };
 
 enum { RPE_FEATURE_ORB = 0, RPE_FEATURE_SIFT = 1 };
+#define RPE_SIFT_UNCAPPED_CAPACITY 16320   /* keypoints per image held when SIFT runs without a cap (nfeatures = 0) */
 enum { RPE_NORM_HAMMING = 0, RPE_NORM_L2 = 1 };
 /* RPE_MATCH_CROSSCHECK = the reference (BFMatcher(norm, crossCheck=True).match, pose_estimator.py:131,144).
  * RPE_MATCH_RATIO = opt-in extension named by the project brief, NOT in the reference: knnMatch(k=2) + Lowe's
@@ -97,7 +98,9 @@ typedef struct rpe_config {
     int32_t feature_method;   /* RPE_FEATURE_ORB        (pose_estimator.py:22) */
     int32_t norm_type;        /* RPE_NORM_HAMMING       (pose_estimator.py:23) */
     int32_t max_matches;      /* default 500            (pose_estimator.py:24); 5 .. 8064; >= nfeatures+64 (the keypoint capacity) = "no truncation" (:150-151) */
-    int32_t nfeatures;        /* default 4000           (pose_estimator.py:25) */
+    int32_t nfeatures;        /* default 4000           (pose_estimator.py:25): ORB 1 .. 8000.  SIFT: 0 = no cap, what the reference's
+                                 cv2.SIFT_create() (pose_estimator.py:93-94) does -- arrays then hold RPE_SIFT_UNCAPPED_CAPACITY
+                                 keypoints per image and RPE_OVF_SIFT_KEYPOINTS reports an image that has more; 1 .. 16320 = SIFT_create(nfeatures) */
     int32_t fast_threshold;   /* 15                     (pose_estimator.py:89) */
     int32_t ransac_max_iters; /* 1000 (cv2 default maxIters) */
     double  ransac_prob;      /* 0.999                  (pose_estimator.py:525) */

@@ -21,6 +21,8 @@ STL_LIBSTDCXX, STL_MSVC = 0, 1          # whose nth_element orders the keypoints
 # capacity flags (rpe_fetch_overflow)
 OVF_ORB_CANDIDATES, OVF_ORB_KEYPOINTS = 1 << 0, 1 << 1
 OVF_SIFT_SEEDS, OVF_SIFT_RAW, OVF_SIFT_PREFILTER, OVF_SIFT_CAP, OVF_SIFT_KEYPOINTS = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
+SIFT_UNCAPPED_CAPACITY = 16320   # RPE_SIFT_UNCAPPED_CAPACITY: keypoints per image kept by SIFT with nfeatures = 0
+MAX_MATCHES_LIMIT = 8064          # rpe_config.max_matches upper bound
 CALIB_KINDS = 16
 STAGE_COUNT = 12
 ORDER_BGR, ORDER_RGB = 0, 1

@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void match_l2_select_kernel(const unsigned lon
                                                                int *__restrict__ m_q, int *__restrict__ m_t, float *__restrict__ m_d,
                                                                int *__restrict__ m_n, float2 *__restrict__ pts1, float2 *__restrict__ pts2)
 {
-    extern __shared__ unsigned long long s_key[];          // sortP <= 8192 keys (64 KB)
+    extern __shared__ unsigned long long s_key[];          // sortP <= 16384 keys (128 KB)
     __shared__ int s_valid;
     const int tid = threadIdx.x, pair = blockIdx.x;
     const int img1 = pair, img2 = img2_base + pair;
@@ -604,6 +604,8 @@ void rpe_launch_match_l2(rpe_handle *h, int B)
 #undef L2_LAUNCH
     int sortP = 64;
     while (sortP < kcap) sortP <<= 1;
+    if (sizeof(unsigned long long) * (size_t)sortP > 65536)   // more than 8128 keypoints per image: up to 128 KB of the CU's 160 KB
+        hipFuncSetAttribute((const void *)match_l2_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned long long) * (size_t)sortP));
     hipLaunchKernelGGL(match_l2_select_kernel, dim3(B), dim3(256), sizeof(unsigned long long) * (size_t)sortP, h->stream,
                        (const unsigned long long *)h->d_m_best, rt ? (const unsigned long long *)nullptr : (const unsigned long long *)h->d_m_best2,
                        h->d_kp_count, h->d_kp_pt, img2_base, kcap, h->cfg.max_matches,

@@ -61,7 +61,9 @@ extern "C" int rpe_keypoint_capacity(const rpe_handle *h) { return h ? h->lay.kc
 static void build_layout(rpe_handle *h)
 {
     RpeDeviceLayout &L = h->lay;
-    const int W = h->cfg.width, H = h->cfg.height, nf = h->cfg.nfeatures;
+    const int W = h->cfg.width, H = h->cfg.height;
+    // SIFT with nfeatures = 0 is cv2's SIFT_create() default: no retainBest; the arrays hold RPE_SIFT_UNCAPPED_CAPACITY keypoints
+    const int nf = (h->cfg.feature_method == RPE_FEATURE_SIFT && h->cfg.nfeatures == 0) ? RPE_SIFT_UNCAPPED_CAPACITY : h->cfg.nfeatures;
     const double sf = (double)1.1f;
     long long off = 0;
     int coef = 0, cand = 0;
@@ -347,17 +349,17 @@ extern "C" int rpe_create(const rpe_config *cfg, rpe_handle **out)
         g_create_err = "NORM_HAMMING needs 8-bit descriptors: SIFT descriptors are float (cv2 raises in match())"; return RPE_ERR_INVALID;
     }
     if (cfg->match_mode != RPE_MATCH_CROSSCHECK && cfg->match_mode != RPE_MATCH_RATIO) { g_create_err = "unknown match mode"; return RPE_ERR_INVALID; }
-    if (cfg->norm_type == RPE_NORM_L2 && cfg->nfeatures > 4032) {
-        // the L2 matcher sorts next_pow2(nfeatures + 64) 64-bit keys in LDS: 4096 keys = 32 KB
-        g_create_err = "NORM_L2: nfeatures must be <= 4032"; return RPE_ERR_INVALID;
+    if (cfg->norm_type == RPE_NORM_L2 && cfg->nfeatures > RPE_SIFT_UNCAPPED_CAPACITY) {
+        // the L2 matcher sorts next_pow2(nfeatures + 64) 64-bit keys in LDS: 16384 keys = 128 KB of the CU's 160
+        g_create_err = "NORM_L2: nfeatures must be <= 16320"; return RPE_ERR_INVALID;
     }
     if (cfg->stl_runtime != RPE_STL_LIBSTDCXX && cfg->stl_runtime != RPE_STL_MSVC) { g_create_err = "unknown stl_runtime"; return RPE_ERR_INVALID; }
     if (cfg->match_mode == RPE_MATCH_RATIO && !(cfg->match_ratio > 0. && cfg->match_ratio <= 1.)) { g_create_err = "match_ratio must be in (0, 1]"; return RPE_ERR_INVALID; }
-    if (is_sift && (cfg->nfeatures > 4032 || cfg->nfeatures < 1 || cfg->width > 4000 || cfg->height > 4000)) {
-        g_create_err = "SIFT: nfeatures (keypoint cap) must be <= 4032 and the image <= 4000 px"; return RPE_ERR_INVALID;
+    if (is_sift && (cfg->nfeatures > RPE_SIFT_UNCAPPED_CAPACITY || cfg->nfeatures < 0 || cfg->width > 4000 || cfg->height > 4000)) {
+        g_create_err = "SIFT: nfeatures must be 0 (no cap: cv2's SIFT_create()) or a cap <= 16320, and the image <= 4000 px"; return RPE_ERR_INVALID;
     }
     if (cfg->width < 96 || cfg->height < 96 || cfg->width > 4095 || cfg->height > 4095 || cfg->max_batch < 1 ||
-        cfg->nfeatures < 1 || cfg->nfeatures > 8000 || cfg->max_matches < 5 || cfg->max_matches > 8064 ||
+        (!is_sift && (cfg->nfeatures < 1 || cfg->nfeatures > 8000)) || cfg->max_matches < 5 || cfg->max_matches > 8064 ||
         cfg->ransac_max_iters < 1 || cfg->ransac_max_iters > 4096 || cfg->fast_threshold < 1 || cfg->fast_threshold > 254) {
         g_create_err = "configuration out of supported range"; return RPE_ERR_INVALID;
     }

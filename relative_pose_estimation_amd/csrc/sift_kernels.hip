@@ -1257,7 +1257,10 @@ int rpe_sift_create(rpe_handle *h)
         dv.nbands = nb > 0 ? nb : 1; dv.bmstride = bo > 0 ? bo : 1;
     }
     const size_t NI = (size_t)h->n_img_cap;
-    S->raw_pad = 16384;                       // sort capacity: candidates after the response prefilter
+    // sort capacity: the K = 2*nfeatures + 1024 candidates the response prefilter lets through (+ ties), or, without a
+    // cap (nfeatures = 0: nothing is filtered), twice the keypoint capacity (an oriented keypoint list is ~1.2x its unique ones)
+    S->raw_pad = 16384;
+    { const int need = dv.nfeatures > 0 ? 2 * dv.nfeatures + 1024 + 2048 : 2 * dv.kcap; while (S->raw_pad < need) S->raw_pad <<= 1; }
     S->n_xtiles = (int)xt.size();
     SCHK(hipMalloc(&S->d_xtiles, sizeof(SiftXTile) * (xt.size() ? xt.size() : 1)));
     if (!xt.empty()) SCHK(hipMemcpy(S->d_xtiles, xt.data(), sizeof(SiftXTile) * xt.size(), hipMemcpyHostToDevice));

@@ -92,13 +92,15 @@ class PoseEstimator:
         if eng is None or eng.max_batch < batch:
             if eng is not None:
                 eng.close()
-            # SIFT: the reference's SIFT_create() is uncapped (nfeatures is documented "ORB only",
-            # pose_estimator.py:41); the GPU workspace needs a bound, so nfeatures caps SIFT too (<= 4032).
-            # When the cap actually removes keypoints the pair carries OVF_SIFT_CAP (last_overflow).
-            nf = min(self.nfeatures, 4032) if self._feature == _capi.FEATURE_SIFT else self.nfeatures
+            # SIFT: the reference's cv2.SIFT_create() takes no arguments (pose_estimator.py:93-94; nfeatures is documented
+            # "ORB only", :41), so nothing is removed by response: nfeatures = 0 asks the library for exactly that.  The
+            # arrays hold SIFT_UNCAPPED_CAPACITY keypoints per image; an image with more carries OVF_SIFT_KEYPOINTS.
+            sift = self._feature == _capi.FEATURE_SIFT
+            nf = 0 if sift else self.nfeatures
+            cap = (_capi.SIFT_UNCAPPED_CAPACITY if sift else nf) + 64
             # max_matches=None is the reference's "no truncation" (pose_estimator.py:150-151): every cross-checked
-            # match is kept, at most one per keypoint = the keypoint capacity nfeatures + 64
-            mm = min(self.max_matches, nf + 64) if self.max_matches is not None else nf + 64
+            # match is kept, at most one per keypoint = the keypoint capacity (the RANSAC tables stop at 8064 matches)
+            mm = min(self.max_matches if self.max_matches is not None else cap, cap, _capi.MAX_MATCHES_LIMIT)
             eng = _capi.Engine(width, height, max_batch=max(batch, self.max_batch), nfeatures=nf,
                                max_matches=mm, device=self.device, feature_method=self._feature, norm_type=self._norm,
                                match_mode=_capi.MATCH_RATIO if self.ratio is not None else _capi.MATCH_CROSSCHECK,

@@ -39,6 +39,22 @@ def test_no_cpu_fallback():
         pe.estimate(np.zeros((480, 640), np.uint8), np.zeros((480, 640), np.uint8))
 
 
+def test_configuration_limits_are_checked_before_the_device():
+    """rpe_create validates the configuration first (no GPU needed): SIFT accepts nfeatures = 0 -- the reference's
+    uncapped cv2.SIFT_create(), pose_estimator.py:93-94 -- and caps up to 16320; ORB needs 1 .. 8000."""
+    from relative_pose_estimation_amd import _capi
+    if _capi.load().rpe_device_count() > 0:
+        pytest.skip("a GPU is present")
+    sift = dict(feature_method=_capi.FEATURE_SIFT, norm_type=_capi.NORM_L2)
+    for kw, msg in ((dict(nfeatures=0), "out of supported range"), (dict(nfeatures=8001), "out of supported range"),
+                    (dict(nfeatures=16321, **sift), "NORM_L2: nfeatures must be <= 16320"), (dict(nfeatures=-1, **sift), "SIFT: nfeatures must be 0"),
+                    (dict(nfeatures=8000, norm_type=_capi.NORM_L2), "no HIP device"),
+                    (dict(nfeatures=0, **sift), "no HIP device"), (dict(nfeatures=16320, **sift), "no HIP device"),
+                    (dict(max_matches=8065), "out of supported range"), (dict(stl_runtime=2), "unknown stl_runtime")):
+        with pytest.raises(_capi.RpeError, match=msg):
+            _capi.Engine(640, 480, **kw)
+
+
 def test_product_never_imports_oracle():
     """the shipped path must not import, link, include or dlopen anything under oracle/"""
     pkg = os.path.join(ROOT, "relative_pose_estimation_amd")

@@ -68,20 +68,26 @@ def test_hd_sift_l2_reference_frames(capi, oracle):
 
 
 def test_sift_cap_is_reported(capi, oracle):
-    """SIFT_create() in the reference is uncapped; a GPU workspace is not.  When nfeatures removes keypoints the pair
-    carries RPE_OVF_SIFT_CAP (GPU == oracle), so a caller can tell that the feature set differs from the reference's."""
+    """SIFT_create(nfeatures) through the C-ABI (an extension: the reference's SIFT_create() has no cap).  When the cap
+    removes keypoints the pair carries RPE_OVF_SIFT_CAP (GPU == oracle), so a caller can tell that the feature set
+    differs from the reference's.  The drop-in class ignores nfeatures for SIFT, as the reference does, and never
+    raises that flag (tests/test_gpu_round3.py::test_sift_without_a_cap)."""
     from relative_pose_estimation_amd import PoseEstimator, synthetic, geometry
     K = geometry.default_camera_matrix(320, 240)
     i1, i2, _, _ = synthetic.make_batch(1, K, 320, 240, cfg=6)
     mask = capi.OVF_SIFT_SEEDS | capi.OVF_SIFT_CAP | capi.OVF_SIFT_KEYPOINTS
-    for nf, want in ((100, capi.OVF_SIFT_CAP), (4000, 0)):
-        pe = PoseEstimator(K, feature_method="SIFT", norm_type="L2", nfeatures=nf, max_matches=80)
-        R, t, inl, st = pe.estimate_batch(i1, i2)
+    for nf, want in ((100, capi.OVF_SIFT_CAP), (4000, 0), (0, 0)):
+        e = capi.Engine(320, 240, max_batch=1, nfeatures=nf, max_matches=80, feature_method=capi.FEATURE_SIFT, norm_type=capi.NORM_L2)
+        R, t, inl, nm, st = e.estimate_batch(i1, i2, K)
         r = oracle.estimate_pose_batch(i1, i2, K, nf, 80, nthreads=1, method="SIFT")[0]
-        ovf = int(pe.last_overflow()[0])
+        ovf = int(e.fetch_overflow(1)[0])
         assert (ovf & mask) == (int(r["overflow"]) & mask) == want, (nf, ovf, r["overflow"])
         assert st[0] == r["status"] == 0 and inl[0] == r["inliers"] and np.array_equal(R[0], r["R"].reshape(3, 3))
-        pe.close()
+        e.close()
+    pe = PoseEstimator(K, feature_method="SIFT", norm_type="L2", nfeatures=100, max_matches=80)      # nfeatures: "ORB only"
+    R, t, inl, st = pe.estimate_batch(i1, i2)
+    assert int(pe.last_overflow()[0]) == 0 and inl[0] == r["inliers"] and np.array_equal(R[0], r["R"].reshape(3, 3))
+    pe.close()
 
 
 def test_hd_orb_reference_defaults(capi, oracle):

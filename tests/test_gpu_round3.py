@@ -179,3 +179,32 @@ def test_orb_on_a_3840x2160_image(oracle):
     kg = kps[0, :cnt[0]]
     assert np.array_equal(kg["lx"], ko["lx"]) and np.array_equal(kg["ly"], ko["ly"]) and np.array_equal(kg["octave"], ko["octave"])
     assert np.array_equal(kg["angle"].view(np.uint32), ko["angle"].view(np.uint32)) and np.array_equal(desc[0, :cnt[0]], do)
+
+
+def test_sift_without_a_cap(oracle):
+    """feature_method="SIFT" as the reference builds it: cv2.SIFT_create() with no arguments (pose_estimator.py:93-94), i.e.
+    no retainBest.  A textured 1920x1080 pair holds ~12.7k keypoints per image, three times what the capped path of
+    rounds 1-2 could keep: keypoints, descriptors, match count and pose of the drop-in class equal the oracle's run with
+    nfeatures = 0, and no capacity flag is raised."""
+    from relative_pose_estimation_amd import PoseEstimator, _capi, synthetic, geometry
+    W, H = 1920, 1080
+    K = geometry.default_camera_matrix(W, H)
+    i1, i2, _, _ = synthetic.make_batch(1, K, W, H, cfg=5)
+    pe = PoseEstimator(K, feature_method="SIFT", norm_type="L2", nfeatures=4000, max_matches=500)   # nfeatures: "ORB only" (:41)
+    d = pe.estimate_with_debug(i1[0], i2[0])
+    assert int(pe.last_overflow()[0]) == 0
+    eng = pe._engines[(H, W)]
+    assert eng.kcap == _capi.SIFT_UNCAPPED_CAPACITY + 64
+    kps, desc, cnt = eng.sift_detect_and_compute(np.stack([i1[0], i2[0]]))
+    for n, img in enumerate((i1[0], i2[0])):
+        ko, do, fo = oracle.sift_detect_and_compute(img, nfeatures=0, cap=eng.kcap, return_flags=True)
+        assert fo == 0 and cnt[n] == len(ko) > 8192, (cnt[n], len(ko))
+        kg = kps[n, :cnt[n]]
+        for f in ("x", "y", "size", "angle", "response"):
+            assert np.array_equal(kg[f].view(np.uint32), ko[f].view(np.uint32)), f
+        assert np.array_equal(kg["octave"], ko["octave"]) and np.array_equal(desc[n, :cnt[n]], do)
+    r = oracle.estimate_pose_batch(i1, i2, K, 0, 500, nthreads=1, method="SIFT")[0]
+    assert r["status"] == 0 and int(r["overflow"]) == 0
+    assert d["num_matches"] == r["n_matches"] and d["inliers"] == r["inliers"]
+    assert np.array_equal(d["R"], r["R"].reshape(3, 3)) and np.array_equal(d["t"].ravel(), r["t"].ravel())
+    pe.close()
