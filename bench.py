@@ -481,6 +481,23 @@ def dropin_operating_points(data, device, workers):
                                           "config": "PoseEstimator(K).estimate(img1, img2): ORB 4000, Hamming crossCheck, top-500, host images in, (R, t) out",
                                           "stage_ms": {k: round(v, 3) for k, v in eng.stage_ms().items() if v > 0.0005}}
         pe.close()
+        if W == 1920:
+            # feature_method="SIFT" as the reference builds it: SIFT_create() without a cap (pose_estimator.py:93-94); this
+            # textured frame holds ~12.7k keypoints per image
+            pe = PoseEstimator(K, feature_method="SIFT", norm_type="L2", device=device)
+            for _ in range(2):
+                d = pe.estimate_with_debug(i1[0], i2[0])
+            ts = []
+            for _ in range(10):
+                t0 = time.perf_counter(); pe.estimate(i1[0], i2[0]); ts.append(time.perf_counter() - t0)
+            eng = pe._engine(H, W, 1)
+            eng.set_profiling(True); pe.estimate(i1[0], i2[0])
+            out["single_pair"][f"{W}x{H}_sift"] = {"ms_per_estimate_call": round(statistics.median(ts) * 1e3, 3), "min_ms": round(min(ts) * 1e3, 3),
+                                                   "config": "PoseEstimator(K, 'SIFT', 'L2').estimate(img1, img2): SIFT without a cap, L2 crossCheck, top-500",
+                                                   "keypoints": [int(c) for c in eng.sift_detect_and_compute(np.stack([i1[0], i2[0]]))[2]], "matches": int(d["num_matches"]),
+                                                   "overflow_flags": int(pe.last_overflow()[0]),
+                                                   "stage_ms": {k: round(v, 3) for k, v in eng.stage_ms().items() if v > 0.0005}}
+            pe.close()
     K, i1, i2 = data["K"], data["i1"], data["i2"]
     B, H, W = i1.shape
     e = _capi.Engine(W, H, max_batch=B, nfeatures=1000, max_matches=500, device=device)

@@ -168,6 +168,7 @@ class PoseEstimator:
         img1 = self._gray(img1); img2 = self._gray(img2)
         eng = self._engine(img1.shape[0], img1.shape[1], 1)
         R, t, inl, nm, st = eng.estimate_batch(img1[None], img2[None], self.K)
+        self._last_n_matches, self._last_engine, self._last_pairs = nm, eng, 1
         self._raise_for(int(st[0]), int(nm[0]))
         R_rel = R[0]
         if self.use_vp_refinement and R_prev is not None:
@@ -178,6 +179,7 @@ class PoseEstimator:
         img1 = self._gray(img1); img2 = self._gray(img2)
         eng = self._engine(img1.shape[0], img1.shape[1], 1)
         R, t, inl, nm, st = eng.estimate_batch(img1[None], img2[None], self.K)
+        self._last_n_matches, self._last_engine, self._last_pairs = nm, eng, 1
         self._raise_for(int(st[0]), int(nm[0]))
         p1, p2 = eng.fetch_matched_points(1)
         n = int(nm[0])
