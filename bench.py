@@ -116,7 +116,7 @@ STAGE_KERNEL = {"pyramid": "pyr_resize_kernel", "fast": "fast_nms_kernel", "angl
 # SIFT reuses the stage slots (csrc/sift_kernels.hip rpe_sift_run)
 SIFT_STAGE_KERNEL = {"pyramid": "sift_blur_fused_kernel", "fast": "sift_extrema_mask_kernel",
                      "select": "sift_adjust_kernel", "harris": "sift_orient_kernel", "keypoints": "sift_finalize_kernel",
-                     "describe": "sift_describe_kernel", "match": "match_l2_nearest_kernel",
+                     "describe": "sift_describe_kernel", "match": "match_l2_mfma_kernel",
                      "ransac": "ransac_*_kernel (group)", "pose": "recover_pose_kernel"}
 # instruction kind of rpe_calibrate_valu that a stage's inner loop is made of (the measured issue roof it is priced against)
 STAGE_CALIB_KIND = {"fast": 4, "pyramid": 5, "angle": 3, "match": 3, "ransac": 6, "pose": 6, "harris": 5, "select": 5, "keypoints": 5,
@@ -403,6 +403,12 @@ def run_workload(args, method, sub, data, rank, world, device, comm_kind):
             rl["matcher"]["mfma"] = {"ops": ops, "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s (int8, dense)", "frac": tops / MFMA_I8_PEAK_TOPS}
             if rl["matcher"]["mfma"]["frac"] > max(rl["matcher"]["frac"], rl["matcher"].get("valu", {}).get("frac", 0.0)):
                 rl["matcher"]["bound"] = "mfma"
+        else:
+            # the L2 matcher: |a-b|^2 = |a'|^2 + |b'|^2 - 2 a'.b' with a' = a - 128 as int8, 4 x v_mfma_i32_32x32x32_i8 per 32 x 32
+            # tile (K = 128), two crossCheck passes; the stage time includes the norms and the select kernels
+            ops = 2 * 2.0 * 128 * args.nfeatures * args.nfeatures * Bl
+            tops = ops / (stage_ms["match"] * 1e-3) / 1e12
+            rl["matcher"]["mfma"] = {"ops": ops, "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s (int8, dense)", "frac": tops / MFMA_I8_PEAK_TOPS}
         if not args.no_calibrate:
             try:
                 rl["hbm_measured_gbs"] = eng.calibrate_hbm() / 1e9

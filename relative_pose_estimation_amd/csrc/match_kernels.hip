@@ -433,10 +433,19 @@ void rpe_launch_match(rpe_handle *h, int B)
 // cv2.BFMatcher(NORM_L2, crossCheck=True) on SIFT descriptors (pose_estimator.py:94,:127-131).
 // SIFT descriptors are integer-valued 0..255 (saturate_cast<uchar> in calcSIFTDescriptor), so
 // they are kept as u8[128] in HBM and the squared distance is EXACT in integers:
-// |a-b|^2 = |a|^2 + |b|^2 - 2 a.b with a.b from 32 x v_dot4_u32_u8.  The reported / compared
-// distance is the f32 sqrt of that integer, exactly what cv2 computes in f32 (sum < 2^24).
-// Same selection semantics as the Hamming kernel; keys are 64-bit because the sort key is
-// the f32 distance (distinct integers can collide after sqrt -> tie broken by index).
+// |a-b|^2 = |a|^2 + |b|^2 - 2 a.b.  The reported / compared distance is the f32 sqrt of that integer, exactly what
+// cv2 computes in f32 (sum < 2^24).  Keys are 64-bit because the sort key is the f32 distance (distinct integers
+// can collide after sqrt -> tie broken by index).
+//
+// crossCheck, as batchDistance runs it (two passes): NNt(i) = the query's nearest train (lowest train on ties),
+// NNq(j) = the train's nearest query (lowest query on ties); (i, NNt(i)) is a match iff NNq(NNt(i)) == i.  Both passes
+// are the same "every OWNED descriptor finds its nearest SCANNED one" loop with the two images swapped; each writes
+// one packed (f32 distance bits << 18 | scanned index) word per owned descriptor, the select kernel joins them.
+//
+// The O(N^2) part runs on the matrix cores (match_l2_mfma_kernel): with a' = a - 128 (a XOR 0x80 per byte: u8 -> i8),
+// |a-b|^2 = |a'|^2 + |b'|^2 - 2 a'.b' and a'.b' is v_mfma_i32_32x32x32_i8 over K = 128 (4 MFMAs per 32 x 32 tile; exact
+// integers).  The vector-ALU kernel below it (32 x v_dot4_u32_u8 per distance) remains for the Lowe-ratio extension,
+// which also needs the second-best distance, and as the A/B diagnostic (RPE_MATCH_VALU).
 #define L2_QTILE 256
 
 // NQ = descriptor bytes / 16: 8 for SIFT (128 B), 2 for ORB descriptors matched with NORM_L2 (32 B; cv2 builds this
@@ -457,13 +466,8 @@ __device__ __forceinline__ unsigned dot_u8(const uint4 *q, const uint4 (&t)[NQ])
     return acc;
 }
 
-// Kernel 1: workgroup = (256 train descriptors, pair).  Every train elects its nearest query over
-// all query tiles; the election lands in HBM through a packed 64-bit atomicMin per query
-// (integer atomics: order independent).  Splitting a pair over its train chunks gives kcap/256 times
-// more workgroups than one workgroup per pair (32-pair HD sub-batches left 7/8 of the CUs idle).
-// MODE 0: crossCheck pass 0 (a lane owns a train and elects its nearest query: atomicMin into best[query]);
-// MODE 2: crossCheck pass 1 (a lane owns a query; its own nearest train goes to best[query], a plain store);
-// MODE 1: Lowe ratio (extension).
+// Vector-ALU form.  Workgroup = (256 owned descriptors, pair); the scanned descriptors stream through LDS.
+// MODE 0: owned = trains (NNq), MODE 2: owned = queries (NNt), MODE 1: Lowe ratio (extension; owned = queries).
 template <int NQ, int MODE>
 __global__ __launch_bounds__(256) void match_l2_nearest_kernel(const uint8_t *__restrict__ desc, const int *__restrict__ kp_count,
                                                                 int img2_base, int kcap, double ratio, unsigned long long *__restrict__ best)
@@ -475,7 +479,6 @@ __global__ __launch_bounds__(256) void match_l2_nearest_kernel(const uint8_t *__
     const int img1 = pair, img2 = img2_base + pair;
     const int n1 = min(kp_count[img1], kcap), n2 = min(kp_count[img2], kcap);
     constexpr bool RATIO = MODE == 1, QOWN = MODE != 0;
-    // crossCheck pass 0: a lane owns a train, queries stream through LDS; pass 1 and ratio: a lane owns a query, trains stream
     const int n_own = QOWN ? n1 : n2, n_scan = QOWN ? n2 : n1;
     if (tc >= n_own || n_scan <= 0) return;
     const uint4 *d1 = (const uint4 *)(desc + (long long)img1 * kcap * DIM);
@@ -524,10 +527,7 @@ __global__ __launch_bounds__(256) void match_l2_nearest_kernel(const uint8_t *__
             }
         }
     }
-    if (MODE == 0) {
-        if (valid && besti >= 0)
-            atomicMin(&best[(long long)pair * kcap + besti], ((unsigned long long)__float_as_uint(bestd) << 18) | (unsigned long long)j);
-    } else if (MODE == 2) {
+    if (!RATIO) {
         if (valid && besti >= 0)
             best[(long long)pair * kcap + j] = ((unsigned long long)__float_as_uint(bestd) << 18) | (unsigned long long)besti;
     } else if (valid && n_scan >= 2 && (double)bestd < ratio * (double)second) {
@@ -535,9 +535,152 @@ __global__ __launch_bounds__(256) void match_l2_nearest_kernel(const uint8_t *__
     }
 }
 
-// Kernel 2: workgroup = pair: stable sort of the elected (distance, queryIdx) keys, first max_matches, point gather.
-// best2 (crossCheck only, nullptr for the ratio mode): the query's own nearest train; the match survives iff the two keys are equal
-__global__ __launch_bounds__(256) void match_l2_select_kernel(const unsigned long long *__restrict__ best, const unsigned long long *__restrict__ best2,
+// Per descriptor a (u = a - 128 per byte): { |u|^2, |u|^2 + 2 sum(u) } -- the owner's and the scanned row's terms of the MFMA kernel
+template <int NQ>
+__global__ __launch_bounds__(256) void match_l2_norms_kernel(const uint8_t *__restrict__ desc, const int *__restrict__ kp_count, int kcap,
+                                                              int2 *__restrict__ norms)
+{
+    const int img = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= min(kp_count[img], kcap)) return;
+    const uint4 *d = (const uint4 *)(desc + ((long long)img * kcap + k) * (NQ * 16));
+    int acc = 0, sum = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const uint4 a = d[q];
+        const int x = (int)(a.x ^ 0x80808080u), y = (int)(a.y ^ 0x80808080u), z = (int)(a.z ^ 0x80808080u), w = (int)(a.w ^ 0x80808080u);
+        acc = __builtin_amdgcn_sdot4(x, x, acc, false); acc = __builtin_amdgcn_sdot4(y, y, acc, false);
+        acc = __builtin_amdgcn_sdot4(z, z, acc, false); acc = __builtin_amdgcn_sdot4(w, w, acc, false);
+        sum = __builtin_amdgcn_sdot4(x, 0x01010101, sum, false); sum = __builtin_amdgcn_sdot4(y, 0x01010101, sum, false);
+        sum = __builtin_amdgcn_sdot4(z, 0x01010101, sum, false); sum = __builtin_amdgcn_sdot4(w, 0x01010101, sum, false);
+    }
+    norms[(long long)img * kcap + k] = make_int2(acc, acc + 2 * sum);
+}
+
+// Matrix-core form of one crossCheck pass.  Workgroup = 4 waves; wave w owns 32 descriptors (tile 4 blockIdx.x + w): the
+// B operand (MFMA columns) of all KS K-steps, in registers.  The scanned descriptors stream through LDS as A-operand
+// tiles of 32 rows (lane l of K-step s holds bytes [32 s + 16 (l >> 5), +16) of row l & 31: a plain 16-byte piece of
+// the descriptor), double buffered, fetched PF tiles ahead.  blockIdx.y deals the scanned tiles over gridDim.y
+// workgroups (small batches: one pair of 12 k x 12 k descriptors fills the chip), blockIdx.z = 2 pair + pass.
+// The owner operand is the one's complement w = -v - 1 = b XOR 0x7F of v = b - 128 (its negative would not fit int8), so
+// u.v = -u.w - sum(u) and |a-b|^2 = |v|^2 + e with e = (|u|^2 + 2 sum(u)) + 2 u.w: one v_lshl_add_u32 per accumulator,
+// the row term comes from the norms kernel, the owner's |v|^2 is a per-lane constant and stays out of the comparison.  cv2 compares f32 distances: sqrtf is monotone, so a row can only win if its e is no larger than
+// the running best's -- or larger by at most 2, when two integers share one f32 square root (only beyond 2^22) and the
+// row has the lower index.  That test runs on the tile minimum; the exact (f32 distance, index) comparison of the
+// 16 rows runs only in a wave where some lane passes it.
+#define L2M_PF 3
+template <int KS>
+__global__ __launch_bounds__(256) void match_l2_mfma_kernel(const uint8_t *__restrict__ desc, const int2 *__restrict__ norms,
+                                                             const int *__restrict__ kp_count, int img2_base, int kcap,
+                                                             unsigned long long *__restrict__ nn_t, unsigned long long *__restrict__ nn_q)
+{
+    constexpr int DIM = KS * 32;
+    __shared__ v4i_t s_a[2][KS][64];
+    __shared__ __attribute__((aligned(16))) int s_qn[2][32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5, col = lane & 31;
+    const int pair = blockIdx.z >> 1, pass = blockIdx.z & 1;
+    const int img1 = pair, img2 = img2_base + pair;
+    const int n1 = min(kp_count[img1], kcap), n2 = min(kp_count[img2], kcap);
+    // pass 0: the queries own the columns and find their nearest train (NNt); pass 1: the trains find their nearest query
+    const int img_own = pass ? img2 : img1, img_scan = pass ? img1 : img2;
+    const int n_own = pass ? n2 : n1, n_scan = pass ? n1 : n2;
+    if (blockIdx.x * 128 >= n_own || n_scan <= 0) return;
+    const int ntq = (n_scan + 31) >> 5;
+    const int per = (ntq + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int qt_lo = (int)blockIdx.y * per, qt_hi = min(ntq, qt_lo + per);
+    if (qt_lo >= qt_hi) return;
+    const uint4 *d_own = (const uint4 *)(desc + (long long)img_own * kcap * DIM);
+    const uint4 *d_scan = (const uint4 *)(desc + (long long)img_scan * kcap * DIM);
+    const int2 *nrm_scan = norms + (long long)img_scan * kcap;
+    const int j = (blockIdx.x * 4 + wv) * 32 + col;
+    const bool valid_own = j < n_own;
+    v4i_t bop[KS];
+#pragma unroll
+    for (int sK = 0; sK < KS; ++sK) {
+        uint4 t = make_uint4(0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu);
+        if (valid_own) t = d_own[(long long)j * (DIM / 16) + 2 * sK + h];
+        bop[sK].x = (int)(t.x ^ 0x7F7F7F7Fu); bop[sK].y = (int)(t.y ^ 0x7F7F7F7Fu); bop[sK].z = (int)(t.z ^ 0x7F7F7F7Fu); bop[sK].w = (int)(t.w ^ 0x7F7F7F7Fu);
+    }
+    const int tn = valid_own ? norms[(long long)img_own * kcap + j].x : 0;
+    // loader: thread (s = tid >> 6, l = tid & 63) brings piece (row l & 31, bytes [32 s + 16 (l >> 5), +16)) of a tile
+    const int xs = tid >> 6, xrow = lane & 31, xh = lane >> 5;
+    const bool loader = xs < KS;
+    auto fetch = [&](int qt) -> uint4 {
+        const int q = qt * 32 + xrow;
+        return (loader && qt < qt_hi && q < n_scan) ? d_scan[(long long)q * (DIM / 16) + 2 * xs + xh] : make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+    };
+    auto fetch_n = [&](int qt) -> int {
+        const int q = qt * 32 + tid;
+        return (tid < 32 && qt < qt_hi && q < n_scan) ? nrm_scan[q].y : 0x3FFFFFFF;     // rows past the end never win
+    };
+    auto stage = [&](int buf, const uint4 &raw, int qn) {
+        if (loader) {
+            v4i_t v; v.x = (int)(raw.x ^ 0x80808080u); v.y = (int)(raw.y ^ 0x80808080u); v.z = (int)(raw.z ^ 0x80808080u); v.w = (int)(raw.w ^ 0x80808080u);
+            s_a[buf][xs][lane] = v;
+        }
+        if (tid < 32) s_qn[buf][tid] = qn;
+    };
+    uint4 ring[L2M_PF]; int ring_n[L2M_PF];
+#pragma unroll
+    for (int u = 0; u < L2M_PF; ++u) { ring[u] = fetch(qt_lo + u); ring_n[u] = fetch_n(qt_lo + u); }
+    stage(0, ring[0], ring_n[0]);
+    ring[0] = fetch(qt_lo + L2M_PF); ring_n[0] = fetch_n(qt_lo + L2M_PF);
+    __syncthreads();
+    int best_e = 0x3FFFFFF0, best_idx = 0x7FFFFFFF;
+    float best_g = __builtin_inff();
+    for (int qt0 = qt_lo; qt0 < qt_hi; qt0 += L2M_PF) {
+#pragma unroll
+        for (int u = 0; u < L2M_PF; ++u) {
+            const int qt = qt0 + u;
+            if (qt < qt_hi) {                                  // workgroup-uniform
+                const int buf = (qt - qt_lo) & 1;
+                v16i_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int sK = 0; sK < KS; ++sK)
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(s_a[buf][sK][lane], bop[sK], acc, 0, 0, 0);
+                // C layout: column = lane & 31, row of register r = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+                int e[16];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const v4i_t qn4 = *(const v4i_t *)&s_qn[buf][8 * g4 + 4 * h];
+                    e[4 * g4 + 0] = (acc[4 * g4 + 0] << 1) + qn4.x; e[4 * g4 + 1] = (acc[4 * g4 + 1] << 1) + qn4.y;
+                    e[4 * g4 + 2] = (acc[4 * g4 + 2] << 1) + qn4.z; e[4 * g4 + 3] = (acc[4 * g4 + 3] << 1) + qn4.w;
+                }
+                int tmin = e[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tmin = min(tmin, e[r]);
+                if (__any(tmin <= best_e + 2)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (e[r] <= best_e + 2) {
+                            const float g = sqrtf((float)(e[r] + tn));
+                            const int idx = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            if (g < best_g || (g == best_g && idx < best_idx)) { best_g = g; best_idx = idx; best_e = e[r]; }
+                        }
+                    }
+                }
+                if (qt + 1 < qt_hi) {
+                    stage(buf ^ 1, ring[(u + 1) % L2M_PF], ring_n[(u + 1) % L2M_PF]);
+                    ring[(u + 1) % L2M_PF] = fetch(qt + 1 + L2M_PF); ring_n[(u + 1) % L2M_PF] = fetch_n(qt + 1 + L2M_PF);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // the two half-waves hold the same columns (different rows)
+    {
+        const float og = __shfl_xor(best_g, 32); const int oi = __shfl_xor(best_idx, 32);
+        if (og < best_g || (og == best_g && oi < best_idx)) { best_g = og; best_idx = oi; }
+    }
+    if (valid_own && h == 0 && best_idx != 0x7FFFFFFF) {
+        unsigned long long *out = (pass ? nn_q : nn_t) + (long long)pair * kcap + j;
+        atomicMin(out, ((unsigned long long)__float_as_uint(best_g) << 18) | (unsigned long long)best_idx);
+    }
+}
+
+// Kernel 2: workgroup = pair: stable sort of the (distance, queryIdx) keys of the surviving matches, first max_matches,
+// point gather.  nn_t[i] = query i's nearest train; nn_q (crossCheck only, nullptr for the ratio mode) = train j's
+// nearest query: the match survives iff nn_q[nn_t[i]] names i
+__global__ __launch_bounds__(256) void match_l2_select_kernel(const unsigned long long *__restrict__ nn_t, const unsigned long long *__restrict__ nn_q,
                                                                const int *__restrict__ kp_count,
                                                                const float2 *__restrict__ kp_pt, int img2_base, int kcap, int max_matches,
                                                                int *__restrict__ m_q, int *__restrict__ m_t, float *__restrict__ m_d,
@@ -548,7 +691,7 @@ __global__ __launch_bounds__(256) void match_l2_select_kernel(const unsigned lon
     const int tid = threadIdx.x, pair = blockIdx.x;
     const int img1 = pair, img2 = img2_base + pair;
     const int n1 = min(kp_count[img1], kcap);
-    const unsigned long long *bp = best + (long long)pair * kcap;
+    const unsigned long long *bp = nn_t + (long long)pair * kcap;
     if (tid == 0) s_valid = 0;
     __syncthreads();
     int sortP = 64;
@@ -558,7 +701,7 @@ __global__ __launch_bounds__(256) void match_l2_select_kernel(const unsigned lon
         unsigned long long key = ~0ull;
         if (i < n1) {
             unsigned long long b = bp[i];
-            if (b != ~0ull && (!best2 || b == best2[(long long)pair * kcap + i])) { key = ((b >> 18) << 16) | (unsigned long long)i; ++myvalid; }
+            if (b != ~0ull && (!nn_q || (int)(nn_q[(long long)pair * kcap + (int)(b & 0x3FFFF)] & 0x3FFFF) == i)) { key = ((b >> 18) << 16) | (unsigned long long)i; ++myvalid; }
         }
         s_key[i] = key;
     }
@@ -593,21 +736,37 @@ void rpe_launch_match_l2(rpe_handle *h, int B)
 {
     const int kcap = h->lay.kcap;
     const int img2_base = h->img2_base ? h->img2_base : B;
-    hipMemsetAsync(h->d_m_best, 0xFF, sizeof(unsigned long long) * (size_t)B * kcap, h->stream);
+    // d_m_best2 = NNt (per query; the ratio mode's only list), d_m_best = NNq (per train)
+    hipMemsetAsync(h->d_m_best2, 0xFF, sizeof(unsigned long long) * (size_t)B * kcap, h->stream);
     const bool rt = h->cfg.match_mode == RPE_MATCH_RATIO;
-    if (!rt) hipMemsetAsync(h->d_m_best2, 0xFE, sizeof(unsigned long long) * (size_t)B * kcap, h->stream);
-    const dim3 grid((kcap + 255) / 256, B);
+    if (!rt) hipMemsetAsync(h->d_m_best, 0xFF, sizeof(unsigned long long) * (size_t)B * kcap, h->stream);
+    const bool sift = h->desc_bytes == 128;
+    if (rt || getenv("RPE_MATCH_VALU")) {
+        const dim3 grid((kcap + 255) / 256, B);
 #define L2_LAUNCH(NQ, MODE, DST) hipLaunchKernelGGL((match_l2_nearest_kernel<NQ, MODE>), grid, dim3(256), 0, h->stream, \
                                                     h->d_desc, h->d_kp_count, img2_base, kcap, h->cfg.match_ratio, DST)
-    if (h->desc_bytes == 128) { if (rt) L2_LAUNCH(8, 1, h->d_m_best); else { L2_LAUNCH(8, 0, h->d_m_best); L2_LAUNCH(8, 2, h->d_m_best2); } }
-    else                      { if (rt) L2_LAUNCH(2, 1, h->d_m_best); else { L2_LAUNCH(2, 0, h->d_m_best); L2_LAUNCH(2, 2, h->d_m_best2); } }
+        if (sift) { if (rt) L2_LAUNCH(8, 1, h->d_m_best2); else { L2_LAUNCH(8, 0, h->d_m_best); L2_LAUNCH(8, 2, h->d_m_best2); } }
+        else      { if (rt) L2_LAUNCH(2, 1, h->d_m_best2); else { L2_LAUNCH(2, 0, h->d_m_best); L2_LAUNCH(2, 2, h->d_m_best2); } }
 #undef L2_LAUNCH
+    } else {
+        const int n_img = img2_base + B;                       // images [0, B) and [img2_base, img2_base + B) (a stream: B + 1 frames)
+        const dim3 gn((kcap + 255) / 256, n_img);
+        if (sift) hipLaunchKernelGGL(match_l2_norms_kernel<8>, gn, dim3(256), 0, h->stream, h->d_desc, h->d_kp_count, kcap, (int2 *)h->d_m_norm);
+        else      hipLaunchKernelGGL(match_l2_norms_kernel<2>, gn, dim3(256), 0, h->stream, h->d_desc, h->d_kp_count, kcap, (int2 *)h->d_m_norm);
+        // scanned tiles dealt over `split` workgroups until ~1024 workgroups are in flight (a single pair included)
+        const int chunks = (kcap + 127) / 128;
+        int split = (1024 + chunks * 2 * B - 1) / (chunks * 2 * B);
+        split = split < 1 ? 1 : split > 8 ? 8 : split;
+        const dim3 grid(chunks, split, 2 * B);
+        if (sift) hipLaunchKernelGGL(match_l2_mfma_kernel<4>, grid, dim3(256), 0, h->stream, h->d_desc, (const int2 *)h->d_m_norm, h->d_kp_count, img2_base, kcap, h->d_m_best2, h->d_m_best);
+        else      hipLaunchKernelGGL(match_l2_mfma_kernel<1>, grid, dim3(256), 0, h->stream, h->d_desc, (const int2 *)h->d_m_norm, h->d_kp_count, img2_base, kcap, h->d_m_best2, h->d_m_best);
+    }
     int sortP = 64;
     while (sortP < kcap) sortP <<= 1;
     if (sizeof(unsigned long long) * (size_t)sortP > 65536)   // more than 8128 keypoints per image: up to 128 KB of the CU's 160 KB
         hipFuncSetAttribute((const void *)match_l2_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned long long) * (size_t)sortP));
     hipLaunchKernelGGL(match_l2_select_kernel, dim3(B), dim3(256), sizeof(unsigned long long) * (size_t)sortP, h->stream,
-                       (const unsigned long long *)h->d_m_best, rt ? (const unsigned long long *)nullptr : (const unsigned long long *)h->d_m_best2,
+                       (const unsigned long long *)h->d_m_best2, rt ? (const unsigned long long *)nullptr : (const unsigned long long *)h->d_m_best,
                        h->d_kp_count, h->d_kp_pt, img2_base, kcap, h->cfg.max_matches,
                        h->d_m_q, h->d_m_t, (float *)h->d_m_d, h->d_m_n, h->d_pts1, h->d_pts2);
 }

@@ -317,7 +317,7 @@ static int alloc_workspace(rpe_handle *h)
     h->d_inliers = (int *)(h->d_t + (size_t)B * 3); h->d_status = h->d_inliers + B; h->d_m_n = h->d_status + B;
     HIPCHK(h, hipHostMalloc((void **)&h->h_resblk, (size_t)B * RPE_RESULT_BYTES));
     DM(h, h->d_pts1, B * mm); DM(h, h->d_pts2, B * mm);
-    if (h->cfg.norm_type == RPE_NORM_L2) { DM(h, h->d_m_best, B * L.kcap); DM(h, h->d_m_best2, B * L.kcap); }
+    if (h->cfg.norm_type == RPE_NORM_L2) { DM(h, h->d_m_best, B * L.kcap); DM(h, h->d_m_best2, B * L.kcap); DM(h, h->d_m_norm, 2 * NI * L.kcap); }
     else {
         // small batches (and, when the fused matcher's LDS would not fit, all batches) keep the election words in HBM
         const bool big = (size_t)L.kcap * 8 + 32768 > 65536;
@@ -399,7 +399,7 @@ extern "C" void rpe_destroy(rpe_handle *h)
                     h->d_hist, h->d_cand_xy, h->d_cand_resp, h->d_cand_count, h->d_kp_xy, h->d_kp_resp, h->d_kp_angle,
                     h->d_kp_pt, h->d_kp_cs, h->d_kp_count, h->d_desc, h->d_m_q, h->d_m_t, h->d_m_d, h->d_resblk, h->d_pts1, h->d_pts2,
                     h->d_subsets, h->d_nit_denom, h->d_nit_round, h->d_rstate, h->d_n1, h->d_n2, h->d_found, h->d_models, h->d_hyp, h->d_counts,
-                    h->d_nmodels, h->d_mask, h->d_E, h->d_K, h->d_m_best, h->d_m_best2, h->d_hm_best, h->d_hm_row, h->d_ovf, h->d_corner, h->d_corner_count, h->d_kp_lvl_count};
+                    h->d_nmodels, h->d_mask, h->d_E, h->d_K, h->d_m_best, h->d_m_best2, h->d_m_norm, h->d_hm_best, h->d_hm_row, h->d_ovf, h->d_corner, h->d_corner_count, h->d_kp_lvl_count};
     for (void *p : ptrs) if (p) hipFree(p);
     if (h->h_resblk) hipHostFree(h->h_resblk);
     for (void *p : h->user_allocs) hipFree(p);

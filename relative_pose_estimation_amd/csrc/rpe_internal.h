@@ -171,9 +171,10 @@ struct rpe_handle {
     uint8_t *d_desc = nullptr;        // [img][kcap][32]
     // matching
     int *d_m_q = nullptr, *d_m_t = nullptr, *d_m_d = nullptr, *d_m_n = nullptr;
-    unsigned long long *d_m_best = nullptr;   // L2 matcher: [pair][kcap] packed (f32 dist bits << 18 | trainIdx) of the best elector
+    unsigned long long *d_m_best = nullptr;   // L2 matcher: [pair][kcap] per train: packed (f32 dist bits << 18 | queryIdx) of its nearest query
+    int *d_m_norm = nullptr;                  // L2 matcher: [img][kcap][2] { |u|^2, |u|^2 + 2 sum(u) }, u = byte - 128, of every descriptor
     unsigned *d_hm_best = nullptr, *d_hm_row = nullptr;   // Hamming matcher, small batches (<= RPE_MATCH_SPLIT_PAIRS pairs): election / own-nearest words in HBM
-    unsigned long long *d_m_best2 = nullptr;  // L2 matcher: [pair][kcap] the same key of the query's own nearest train (second crossCheck pass)
+    unsigned long long *d_m_best2 = nullptr;  // L2 matcher: [pair][kcap] per query: the same key of its nearest train (the ratio mode's only list)
     float2 *d_pts1 = nullptr, *d_pts2 = nullptr;   // [pair][max_matches]
     // RANSAC
     unsigned short *d_subsets = nullptr;  // [M 0..max_matches][iters][5]

@@ -238,7 +238,7 @@ def test_ragged_batch_with_failures(capi, oracle, pairs, K_vga):
 # ------------------------------------------------------------------ SIFT + L2 (BASELINE config 3)
 @pytest.fixture(scope="module")
 def eng_sift(capi):
-    e = capi.Engine(320, 240, max_batch=2, nfeatures=600, max_matches=300,
+    e = capi.Engine(320, 240, max_batch=3, nfeatures=600, max_matches=300,
                     feature_method=capi.FEATURE_SIFT, norm_type=capi.NORM_L2)
     yield e
     e.close()
@@ -250,8 +250,15 @@ def test_l2_matcher_bit_exact(eng_sift, oracle):
     b[:120] = a[rng.permutation(500)[:120]]                     # exact duplicates: distance-0 ties
     b[120:200] = np.clip(b[40:120] + rng.integers(-1, 2, (80, 128)), 0, 255)
     a2 = rng.integers(0, 8, (64, 128)).astype(np.float32); b2 = rng.integers(0, 8, (70, 128)).astype(np.float32)  # sqrt collisions
-    q, t, d, nm = eng_sift.match_l2([a, a2], [500, 64], [b, b2], [430, 70])
-    for i, (x, y) in enumerate(((a, b), (a2, b2))):
+    # distances beyond 2^22: neighbouring integers share one f32 square root, and cv2 compares the f32 values -- the lower
+    # index wins where an integer comparison would pick the smaller sum
+    a3 = np.zeros((96, 128), np.float32); b3 = np.full((90, 128), 255, np.float32)
+    a3[:, 100:] = rng.integers(0, 2, (96, 28)); b3[:, 100:] = rng.integers(0, 2, (90, 28))
+    d2 = ((a3[:, None, :].astype(np.int64) - b3[None].astype(np.int64)) ** 2).sum(-1)
+    g = np.sqrt(d2.astype(np.float32))
+    assert (np.argmin(d2, 1) != np.argmin(g, 1)).any() and (np.argmin(d2, 0) != np.argmin(g, 0)).any()
+    q, t, d, nm = eng_sift.match_l2([a, a2, a3], [500, 64, 96], [b, b2, b3], [430, 70, 90])
+    for i, (x, y) in enumerate(((a, b), (a2, b2), (a3, b3))):
         qo, to, do = oracle.match_l2(x, y, 300)
         assert nm[i] == len(qo)
         assert np.array_equal(q[i, :nm[i]], qo) and np.array_equal(t[i, :nm[i]], to)
