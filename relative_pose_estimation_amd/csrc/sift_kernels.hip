@@ -68,6 +68,9 @@ struct RpeSiftState {
     float *d_surv = nullptr; int *d_nsurv = nullptr;        // [img][seed_cap][SURV_W] refined seeds, [img]
     unsigned long long *d_k0 = nullptr, *d_k1 = nullptr; unsigned *d_sidx = nullptr; // sort keys [img][raw_pad]
     int raw_pad = 0;
+    int group = 0, group_octaves = 1;                     // image-major schedule (rpe_sift_run): images per group, octaves inside it
+    bool fused_all = false;                                // every blur radius has a fused instantiation
+    int xtile_oct_end[12] = {0};                           // tiles of octaves 0 .. o end here in d_xtiles
     int ks[6] = {0, 0, 0, 0, 0, 0};                      // tap counts of c_skern
     float *d_fin = nullptr;                                // [img][kcap][6] un-halved keypoints in sorted order
 };
@@ -1247,12 +1250,14 @@ int rpe_sift_create(rpe_handle *h)
         for (int o = 0; o < 12; ++o) { dv.band0[o] = 0; dv.wpr[o] = 0; dv.bmoff[o] = 0; }
         for (int o = 0; o < dv.noct; ++o) {
             dv.band0[o] = nb; dv.wpr[o] = (dv.w[o] + 63) / 64; dv.bmoff[o] = bo;
+            S->xtile_oct_end[o] = (int)xt.size();
             if (dv.w[o] <= 2 * S_BORDER || dv.h[o] <= 2 * S_BORDER) continue;
             nb += S_NOL * (dv.h[o] - 2 * S_BORDER);
             bo += (long long)S_NOL * dv.h[o] * dv.wpr[o];
             for (int y = 0; y < dv.h[o] - S_BORDER; y += SX_TH)
                 for (int x = 0; x < dv.w[o] - S_BORDER; x += SX_TW)
                     if (y + SX_TH > S_BORDER && x + SX_TW > S_BORDER) xt.push_back({o, x, y});
+            S->xtile_oct_end[o] = (int)xt.size();
         }
         dv.nbands = nb > 0 ? nb : 1; dv.bmstride = bo > 0 ? bo : 1;
     }
@@ -1271,6 +1276,9 @@ int rpe_sift_create(rpe_handle *h)
         bool need_tmp = (ks[0] >> 1) != 5;
         for (int i = 0; i < S_NG; ++i) { const int r = ks[i] >> 1; if (r != 5 && r != 6 && r != 8 && r != 10 && r != 13) need_tmp = true; }
         if (need_tmp) SCHK(hipMalloc(&S->d_tmp, sizeof(float) * NI * dv.tstride * 2));
+        S->fused_all = !need_tmp;
+        if (const char *e = getenv("RPE_SIFT_GROUP")) S->group = atoi(e);
+        if (const char *e = getenv("RPE_SIFT_GROUP_OCTAVES")) S->group_octaves = atoi(e) > 0 ? atoi(e) : 1;
     }
     SCHK(hipMalloc(&S->d_band_cnt, sizeof(int) * NI * dv.nbands));
     SCHK(hipMalloc(&S->d_band_off, sizeof(int) * NI * dv.nbands));
@@ -1357,44 +1365,72 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
     // scan, SELECT = adjustLocalExtrema, HARRIS = orientation histograms, KEYPOINTS = prefilter + sort + retainBest,
     // DESCRIBE = descriptors; NMS / ANGLE / BLUR are empty
     MARK(h, RPE_STAGE_PYRAMID);
-    // 1. upsample + initial blur -> gaussian[0][0]: one kernel (the upsampled image is formed in the blur's window loader);
-    //    the separate upsample kernel only feeds the unfused fallback for an unexpected tap count
     const int n = na + nb;
-    if ((S->ks[0] >> 1) == 5) {
-        sift_blur_launch<5, true>(h, nullptr, 0, S->d_gauss + dv.goff[0], dv.gstride, nullptr, 0, bw, bh, 0, n, d_a, d_b, na);
-    } else {
-        for (int part = 0; part < 2; ++part) {
-            const uint8_t *src = part ? d_b : d_a; const int cnt = part ? nb : na, first = part ? na : 0;
-            if (!cnt) continue;
-            hipLaunchKernelGGL(sift_upsample_kernel, dim3((bw / 4 + 256) / 256, H + 1, cnt), dim3(256), 0, h->stream, src, W, H, img,
-                               S->d_tmp + (long long)first * dv.tstride, dv.tstride);
+    // Pyramid of images [i0, i0 + g), octaves [o0, o1).  Octave 0 starts with the upsample + initial blur in one kernel (the
+    // upsampled image is formed in the blur's window loader; the separate upsample kernel only feeds the unfused fallback
+    // for an unexpected tap count); level 0 of octave o + 1 (= level S_NOL of octave o, halved) is written by the blur that
+    // makes that level.
+    auto pyramid = [&](int i0, int g, int o0, int o1) {
+        float *G = S->d_gauss + (long long)i0 * dv.gstride;
+        bool have_l0 = true;
+        if (o0 == 0) {
+            if ((S->ks[0] >> 1) == 5) {
+                const int na_g = na - i0 < 0 ? 0 : na - i0 > g ? g : na - i0;
+                sift_blur_launch<5, true>(h, nullptr, 0, G + dv.goff[0], dv.gstride, nullptr, 0, bw, bh, 0, g,
+                                          d_a + (size_t)i0 * img, d_b + (size_t)(i0 > na ? i0 - na : 0) * img, na_g);
+            } else {
+                for (int part = 0; part < 2; ++part) {
+                    const uint8_t *src = part ? d_b : d_a; const int cnt = part ? nb : na, first = part ? na : 0;
+                    if (!cnt) continue;
+                    hipLaunchKernelGGL(sift_upsample_kernel, dim3((bw / 4 + 256) / 256, H + 1, cnt), dim3(256), 0, h->stream, src, W, H, img,
+                                       S->d_tmp + (long long)first * dv.tstride, dv.tstride);
+                }
+                sift_blur(h, S->d_tmp, dv.tstride, S->d_gauss + dv.goff[0], dv.gstride, nullptr, 0, bw, bh, 0, n);
+            }
         }
-        sift_blur(h, S->d_tmp, dv.tstride, S->d_gauss + dv.goff[0], dv.gstride, nullptr, 0, bw, bh, 0, n);
-    }
-    // 2. gaussian pyramid; level 0 of octave o + 1 (= level S_NOL of octave o, halved) is written by the blur that makes that level
-    bool have_l0 = true;                                   // octave 0: made by step 1
-    for (int o = 0; o < dv.noct; ++o) {
-        const int w = dv.w[o], hh = dv.h[o];
-        const long long pn = (long long)w * hh;
-        if (!have_l0)
-            hipLaunchKernelGGL(sift_halve_kernel, dim3((w + 1023) / 1024, hh, n), dim3(256), 0, h->stream,
-                               (const float *)(S->d_gauss + dv.goff[o - 1] + (long long)S_NOL * dv.w[o - 1] * dv.h[o - 1]),
-                               S->d_gauss + dv.goff[o], dv.gstride, dv.w[o - 1], w, hh);
-        have_l0 = false;
-        for (int i = 1; i < S_NG; ++i) {
-            const bool last = o + 1 >= dv.noct;
-            float *dec = i == S_NOL && !last ? S->d_gauss + dv.goff[o + 1] : nullptr;
-            const bool wrote = sift_blur(h, S->d_gauss + dv.goff[o] + (i - 1) * pn, dv.gstride, S->d_gauss + dv.goff[o] + i * pn, dv.gstride,
-                                         nullptr, 0, w, hh, i, n, dec, last ? 0 : dv.w[o + 1], last ? 0 : dv.h[o + 1]);
-            if (i == S_NOL) have_l0 = wrote;
+        for (int o = o0; o < o1; ++o) {
+            const int w = dv.w[o], hh = dv.h[o];
+            const long long pn = (long long)w * hh;
+            if (!have_l0)
+                hipLaunchKernelGGL(sift_halve_kernel, dim3((w + 1023) / 1024, hh, g), dim3(256), 0, h->stream,
+                                   (const float *)(G + dv.goff[o - 1] + (long long)S_NOL * dv.w[o - 1] * dv.h[o - 1]),
+                                   G + dv.goff[o], dv.gstride, dv.w[o - 1], w, hh);
+            have_l0 = false;
+            for (int i = 1; i < S_NG; ++i) {
+                const bool last = o + 1 >= dv.noct;
+                float *dec = i == S_NOL && !last ? G + dv.goff[o + 1] : nullptr;
+                const bool wrote = sift_blur(h, G + dv.goff[o] + (i - 1) * pn, dv.gstride, G + dv.goff[o] + i * pn, dv.gstride,
+                                             nullptr, 0, w, hh, i, g, dec, last ? 0 : dv.w[o + 1], last ? 0 : dv.h[o + 1]);
+                if (i == S_NOL) have_l0 = wrote;
+            }
         }
-    }
-    // 3. seeds (count, scan, emit)
-    MARK(h, RPE_STAGE_FAST);
+    };
+    // extrema scan of tiles [t0, t0 + nt) of images [i0, i0 + g)
+    auto extrema = [&](int i0, int g, int t0, int nt) {
+        if (nt > 0)
+            hipLaunchKernelGGL(sift_extrema_mask_kernel, dim3((nt + 7) / 8 * 8, g), dim3(256), 0, h->stream,
+                               (const float *)(S->d_gauss + (long long)i0 * dv.gstride), dv, (const SiftXTile *)(S->d_xtiles + t0),
+                               S->d_xmask + (long long)i0 * dv.bmstride, S->d_band_cnt + (long long)i0 * dv.nbands, nt);
+    };
     hipMemsetAsync(S->d_band_cnt, 0, sizeof(int) * (size_t)n * dv.nbands, h->stream);
-    if (S->n_xtiles)
-        hipLaunchKernelGGL(sift_extrema_mask_kernel, dim3((S->n_xtiles + 7) / 8 * 8, n), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
-                           (const SiftXTile *)S->d_xtiles, S->d_xmask, S->d_band_cnt, S->n_xtiles);
+    if (S->group > 0 && S->fused_all && dv.noct > 1) {
+        // image-major schedule for the large octaves: the six levels of octave 0 of a few images (199 MB each at 1920x1080) are
+        // written, read by the next blur and scanned for extrema while they are still in the 256 MB memory-side cache
+        const int om = S->group_octaves < dv.noct ? S->group_octaves : dv.noct;
+        for (int i0 = 0; i0 < n; i0 += S->group) {
+            const int g = n - i0 < S->group ? n - i0 : S->group;
+            pyramid(i0, g, 0, om);
+            extrema(i0, g, 0, S->xtile_oct_end[om - 1]);
+        }
+        if (om < dv.noct) pyramid(0, n, om, dv.noct);
+        MARK(h, RPE_STAGE_FAST);
+        extrema(0, n, S->xtile_oct_end[om - 1], S->n_xtiles - S->xtile_oct_end[om - 1]);
+    } else {
+        pyramid(0, n, 0, dv.noct);
+        // 3. seeds (count, scan, emit)
+        MARK(h, RPE_STAGE_FAST);
+        extrema(0, n, 0, S->n_xtiles);
+    }
     hipMemsetAsync(h->d_ovf, 0, sizeof(unsigned) * n, h->stream);
     hipLaunchKernelGGL(sift_band_scan_kernel, dim3(n), dim3(256), 0, h->stream, (const int *)S->d_band_cnt, S->d_band_off, S->d_nseeds, h->d_ovf, dv);
     hipLaunchKernelGGL(sift_extrema_emit_kernel, dim3((dv.nbands + 3) / 4, n), dim3(256), 0, h->stream, (const unsigned long long *)S->d_xmask, dv,
