@@ -329,9 +329,9 @@ static void sift_descriptor(const float *img, int w, int h, float ptx, float pty
     const int HL = (d + 2) * (d + 2) * (n + 2);
     float part[360][8];
     memset(part, 0, sizeof(part));
-    int k = 0;
+    int k = 0;                                               /* counts the samples that pass the window test, as cv2's first loop does */
     for (int i = -radius; i <= radius; ++i)
-        for (int j = -radius; j <= radius; ++j, ++k) {
+        for (int j = -radius; j <= radius; ++j) {
             float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
             float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
             int r = py + i, c = px + j;
@@ -355,6 +355,7 @@ static void sift_descriptor(const float *img, int w, int h, float ptx, float pty
             part[idx + (n + 2)][L] += v010; part[idx + (n + 3)][L] += v011;
             part[idx + (d + 2) * (n + 2)][L] += v100; part[idx + (d + 2) * (n + 2) + 1][L] += v101;
             part[idx + (d + 3) * (n + 2)][L] += v110; part[idx + (d + 3) * (n + 2) + 1][L] += v111;
+            ++k;
         }
     float hist[360];
     for (int b = 0; b < HL; ++b) hist[b] = tree8(part[b]);

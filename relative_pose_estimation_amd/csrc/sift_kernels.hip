@@ -1081,9 +1081,13 @@ __global__ __launch_bounds__(256) void sift_finalize_kernel(const float *__restr
 __global__ __launch_bounds__(64 * SIFT_DESC_KPW) void sift_describe_kernel(const float *__restrict__ gauss, SiftDev dv, const float *__restrict__ fin,
                                                              const int *__restrict__ kp_count, uint8_t *__restrict__ desc)
 {
-    __shared__ float s_part[SIFT_DESC_KPW][360][8];
-    __shared__ float s_hist[SIFT_DESC_KPW][360];
+    // accumulators of the 4 x 4 inner cells only: the border cells of calcSIFTDescriptor's 6 x 6 x 10 histogram are never read
+    // (each (bin, slot) accumulator is independent, so leaving them out changes nothing that is), and 5 KB instead of 11.5 KB
+    // per keypoint decide how many workgroups a CU holds
+    __shared__ float s_part[SIFT_DESC_KPW][160][8];
+    __shared__ float s_hist[SIFT_DESC_KPW][160];
     __shared__ float s_stage[SIFT_DESC_KPW][64 * 9];
+    __shared__ unsigned s_list[SIFT_DESC_KPW][64 * 9];     // raster indices of the samples inside the rotated grid, not yet consumed (< 64 + 64 DCH)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int kidx = blockIdx.x * SIFT_DESC_KPW + wv, img = blockIdx.y;
     if (kidx >= kp_count[img]) return;
@@ -1109,39 +1113,63 @@ __global__ __launch_bounds__(64 * SIFT_DESC_KPW) void sift_describe_kernel(const
     cos_t /= hist_width; sin_t /= hist_width;
     float (*part)[8] = s_part[wv];
     float *stg = s_stage[wv];
-    for (int i = lane; i < 360 * 8; i += 64) (&part[0][0])[i] = 0.f;
+    for (int i = lane; i < 160 * 8; i += 64) (&part[0][0])[i] = 0.f;
     S_WAVE_SYNC();
     const int side = 2 * radius + 1, nsamp = side * side;
     const float inv_side = 1.f / (float)side;
-    // DU batches of 64 samples per trip: the 4*DU gradient loads of a lane are issued before anything
-    // consumes them (the loop was one exposed L2/HBM round trip per 64 samples)
-    constexpr int DU = 4;
-    for (int k0 = 0; k0 < nsamp; k0 += 64 * DU) {
+    // Two phases per chunk of 64 * DCH raster positions of the bounding square.  Phase 1 tests every position against the rotated
+    // 4 x 4 grid and the image border (calcSIFTDescriptor's first loop) and appends the raster indices of those that pass to an
+    // LDS list, in raster order (ballot + prefix count): only half of the square lies inside the rotated grid.  Phase 2 takes
+    // the list 64 entries at a time -- dense batches: every lane has a sample -- and does the expensive part (gradient loads,
+    // exp, atan2, trilinear weights, accumulation).  Sample number k counts the samples that passed, as cv2's arrays do.
+    constexpr int DCH = 8;
+    constexpr int DU = 4;                                   // dense batches whose gradient loads fly together
+    unsigned *lst = s_list[wv];
+    int pending = 0;                                        // list entries not yet consumed (wave-uniform)
+    auto locate = [&](int k, float &crot, float &rrot, float &rbn, float &cbn, int &r, int &c) {
+        // k / side without the integer divider: float estimate, one correction step (k < 2^24)
+        int qi = (int)((float)k * inv_side);
+        int rem = k - qi * side;
+        if (rem < 0) { --qi; rem += side; } else if (rem >= side) { ++qi; rem -= side; }
+        const int i = qi - radius, j = rem - radius;
+        crot = j * cos_t - i * sin_t; rrot = j * sin_t + i * cos_t;
+        rbn = rrot + d / 2 - 0.5f; cbn = crot + d / 2 - 0.5f;
+        r = py + i; c = px + j;
+    };
+    for (int k0 = 0; k0 < nsamp; k0 += 64 * DCH) {
+#pragma unroll
+        for (int u = 0; u < DCH; ++u) {
+            if (k0 + 64 * u >= nsamp) break;                                  // wave-uniform
+            const int k = k0 + 64 * u + lane;
+            float crot, rrot, rbn, cbn; int r, c;
+            locate(k, crot, rrot, rbn, cbn, r, c);
+            const bool ok = k < nsamp && rbn > -1 && rbn < d && cbn > -1 && cbn < d && r > 0 && r < h - 1 && c > 0 && c < w - 1;
+            const unsigned long long m = __ballot(ok);
+            if (ok) lst[pending + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned)k;
+            pending += __popcll(m);
+        }
+        S_WAVE_SYNC();
+        const bool last_chunk = k0 + 64 * DCH >= nsamp;
+        const int nb = last_chunk ? (pending + 63) >> 6 : pending >> 6;
+        for (int b0 = 0; b0 < nb; b0 += DU) {
         bool vld[DU];
         float crot[DU], rrot[DU], rbn[DU], cbn[DU], g0[DU], g1[DU], g2[DU], g3[DU];
 #pragma unroll
         for (int u = 0; u < DU; ++u) {
-            const int k = k0 + 64 * u + lane;
-            // k / side without the integer divider: float estimate, one correction step (k < 2^24)
-            int qi = (int)((float)k * inv_side);
-            int rem = k - qi * side;
-            if (rem < 0) { --qi; rem += side; } else if (rem >= side) { ++qi; rem -= side; }
-            const int i = qi - radius, j = rem - radius;
-            crot[u] = j * cos_t - i * sin_t; rrot[u] = j * sin_t + i * cos_t;
-            rbn[u] = rrot[u] + d / 2 - 0.5f; cbn[u] = crot[u] + d / 2 - 0.5f;
-            const int r = py + i, c = px + j;
-            vld[u] = k < nsamp && rbn[u] > -1 && rbn[u] < d && cbn[u] > -1 && cbn[u] < d && r > 0 && r < h - 1 && c > 0 && c < w - 1;
-            g0[u] = g1[u] = g2[u] = g3[u] = 0.f;
+            const int e = (b0 + u) * 64 + lane;
+            vld[u] = b0 + u < nb && e < pending;
+            g0[u] = g1[u] = g2[u] = g3[u] = 0.f; crot[u] = rrot[u] = rbn[u] = cbn[u] = 0.f;
             if (vld[u]) {
+                int r, c;
+                locate((int)lst[e], crot[u], rrot[u], rbn[u], cbn[u], r, c);
                 const float *pc = img_l + (size_t)r * w + c;
                 g0[u] = pc[1]; g1[u] = pc[-1]; g2[u] = pc[-w]; g3[u] = pc[w];
             }
         }
 #pragma unroll
         for (int u = 0; u < DU; ++u) {
-        if (k0 + 64 * u >= nsamp) break;                                  // wave-uniform
+        if (b0 + u >= nb) break;                                          // wave-uniform
         const bool valid = vld[u];
-        if (__ballot(valid) == 0) continue;        // 64 samples outside the rotated 4x4 grid (rows near the corners of its bounding square)
         int idx = 0;
         float v000 = 0, v001 = 0, v010 = 0, v011 = 0, v100 = 0, v101 = 0, v110 = 0, v111 = 0;
         if (valid) {
@@ -1163,7 +1191,12 @@ __global__ __launch_bounds__(64 * SIFT_DESC_KPW) void sift_describe_kernel(const
                 const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
                 v111 = v_rc11 * obin; v110 = v_rc11 - v111; v101 = v_rc10 * obin; v100 = v_rc10 - v101;
                 v011 = v_rc01 * obin; v010 = v_rc01 - v011; v001 = v_rc00 * obin; v000 = v_rc00 - v001;
-                idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
+                // compact address of corner (0, 0, 0) (may lie outside: + 64 keeps it positive) and which of the four
+                // (row, column) corners fall on inner cells
+                const int rr0 = r0 + 1, cc0 = c0 + 1;              // 0 .. 4 in the 6 x 6 grid
+                const int mrow = (rr0 >= 1 ? 1 : 0) | (rr0 <= 3 ? 2 : 0), mcol = (cc0 >= 1 ? 1 : 0) | (cc0 <= 3 ? 2 : 0);
+                const int mask = ((mrow & 1) && (mcol & 1) ? 1 : 0) | ((mrow & 1) && (mcol & 2) ? 2 : 0) | ((mrow & 2) && (mcol & 1) ? 4 : 0) | ((mrow & 2) && (mcol & 2) ? 8 : 0);
+                idx = (((rr0 - 1) * 4 + (cc0 - 1)) * (n + 2) + o0 + 64) | (mask << 16);
             }
         }
         // Accumulation: sample k adds its 8 trilinear corners to slot (k & 7) of 8 distinct bins, and every
@@ -1176,7 +1209,7 @@ __global__ __launch_bounds__(64 * SIFT_DESC_KPW) void sift_describe_kernel(const
         S_WAVE_SYNC();
         {
             const int sl = lane & 7, q = lane >> 3;
-            const int qoff = (q & 1) + ((q >> 1) & 1) * (n + 2) + (q >> 2) * (d + 2) * (n + 2);
+            const int qoff = (q & 1) + ((q >> 1) & 1) * (n + 2) + (q >> 2) * d * (n + 2) - 64;
             // the 16 staged values of this lane's 8 steps are read in one go (they do not depend on the accumulators);
             // the steps themselves stay sequential: corners of different samples share bins
             int ids[8]; float vs[8];
@@ -1184,15 +1217,27 @@ __global__ __launch_bounds__(64 * SIFT_DESC_KPW) void sift_describe_kernel(const
             for (int st = 0; st < 8; ++st) { ids[st] = __float_as_int(stg[(sl + 8 * st) * 9]); vs[st] = stg[(sl + 8 * st) * 9 + 1 + q]; }
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
-                if (ids[st] >= 0) part[ids[st] + qoff][sl] = part[ids[st] + qoff][sl] + vs[st];
+                if (ids[st] >= 0 && ((ids[st] >> (16 + (q >> 1))) & 1)) {
+                    const int ad = (ids[st] & 0xFFFF) + qoff;
+                    part[ad][sl] = part[ad][sl] + vs[st];
+                }
                 S_WAVE_SYNC();
             }
         }
         }
+        }
+        if (!last_chunk) {                                  // the incomplete batch moves to the front of the list
+            const int rem = pending & 63;
+            const unsigned keep = lane < rem ? lst[nb * 64 + lane] : 0u;
+            S_WAVE_SYNC();
+            if (lane < rem) lst[lane] = keep;
+            S_WAVE_SYNC();
+            pending = rem;
+        }
     }
     S_WAVE_SYNC();
     float *hist = s_hist[wv];
-    for (int b = lane; b < 360; b += 64) {
+    for (int b = lane; b < 160; b += 64) {
         float p0 = part[b][0], p1 = part[b][1], p2 = part[b][2], p3 = part[b][3], p4 = part[b][4], p5 = part[b][5], p6 = part[b][6], p7 = part[b][7];
         p0 = p0 + p4; p1 = p1 + p5; p2 = p2 + p6; p3 = p3 + p7;
         p0 = p0 + p2; p1 = p1 + p3;
@@ -1203,8 +1248,8 @@ __global__ __launch_bounds__(64 * SIFT_DESC_KPW) void sift_describe_kernel(const
     float dv0, dv1;
     {
         auto elem = [&](int e) {
-            const int ij = e >> 3, kb = e & 7, i = ij >> 2, j = ij & 3;
-            const int id = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
+            const int ij = e >> 3, kb = e & 7;
+            const int id = ij * (n + 2);
             float v = hist[id + kb];
             if (kb < 2) v = v + hist[id + n + kb];
             return v;
