@@ -66,6 +66,7 @@ struct RpeSiftState {
     float *d_raw = nullptr;                                // [img][raw_cap][6]: x y size angle response octave(bits)
     int *d_nraw = nullptr, *d_overflow = nullptr, *d_ncand = nullptr;
     float *d_surv = nullptr; int *d_nsurv = nullptr;        // [img][seed_cap][SURV_W] refined seeds, [img]
+    unsigned *d_sel = nullptr; int *d_nsel = nullptr;       // [img][seed_cap] survivors that get an orientation (sift_select_kernel), [img][2] = {count, cut}
     unsigned long long *d_k0 = nullptr, *d_k1 = nullptr; unsigned *d_sidx = nullptr; // sort keys [img][raw_pad]
     int raw_pad = 0;
     int group = 0, group_octaves = 1;                     // image-major schedule (rpe_sift_run): images per group, octaves inside it
@@ -716,12 +717,62 @@ __global__ __launch_bounds__(256) void sift_adjust_kernel(const float *__restric
     q[1] = xi; q[2] = xr; q[3] = xc; q[4] = contr;
 }
 
+// retainBest(nfeatures) keeps the strongest responses, and a keypoint's response (|contrast|) is known before its orientation
+// is: only the sel_k = nfeatures * 5/4 + 256 strongest survivors (ties included) get an orientation histogram -- a quarter
+// of the ~10 k survivors of a textured HD frame at nfeatures = 2048.  Exact as long as those produce >= nfeatures unique
+// keypoints (every survivor yields one or more, except a histogram whose maximum is a plateau): then the nfeatures-th best
+// response, the threshold of retainBest, lies inside the selected set and nothing below it could have been kept.  Otherwise
+// sift_finalize_kernel raises RPE_OVF_SIFT_PREFILTER.  sel_k = 0 (no cap): every survivor is selected.
+__device__ __forceinline__ unsigned s_float_key(float f);
+__global__ __launch_bounds__(256) void sift_select_kernel(const float *__restrict__ surv, const int *__restrict__ nsurv, SiftDev dv, int sel_k,
+                                                           unsigned *__restrict__ sel, int *__restrict__ nsel)
+{
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_prefix;
+    __shared__ int s_kk, s_cnt;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int n = min(nsurv[img], dv.seed_cap);
+    const float *sv = surv + (long long)img * dv.seed_cap * SURV_W;
+    unsigned *out = sel + (long long)img * dv.seed_cap;
+    unsigned thr_key = 0;
+    if (sel_k > 0 && n > sel_k) {
+        unsigned prefix = 0, mask = 0;
+        if (tid == 0) s_kk = sel_k;
+        for (int pass = 3; pass >= 0; --pass) {
+            const int shift = 8 * pass;
+            s_hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += 256) {
+                const unsigned key = s_float_key(fabsf(sv[(long long)i * SURV_W + 4]));
+                if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int kk = s_kk, acc = 0, bin = 0;
+                for (int b = 255; b >= 0; --b) { int c = (int)s_hist[b]; if (acc + c >= kk) { bin = b; break; } acc += c; }
+                s_kk = kk - acc;
+                s_prefix = prefix | ((unsigned)bin << shift);
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            mask |= 255u << shift;
+        }
+        thr_key = prefix;
+    }
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256)
+        if (s_float_key(fabsf(sv[(long long)i * SURV_W + 4])) >= thr_key) out[atomicAdd(&s_cnt, 1)] = (unsigned)i;   // order is irrelevant: the keypoints are sorted later
+    __syncthreads();
+    if (tid == 0) { nsel[2 * img] = s_cnt; nsel[2 * img + 1] = s_cnt < n ? 1 : 0; }
+}
+
 // One wave per workgroup: survivors differ in window size (6 to 14+ batches of 64 samples), and a 4-wave workgroup
 // holds its wave slots and LDS until its slowest wave is done.
 #define SIFT_ORI_WPW 1
 #define S_ORI_RMAX1 20      // radius + 1 <= 18: radius = round(4.5 * 1.6 * 2^((l + xi) / 3)), l <= 3, |xi| < 0.5 -> <= 17
 __global__ __launch_bounds__(64 * SIFT_ORI_WPW) void sift_orient_kernel(const float *__restrict__ gauss, SiftDev dv,
-                                                           const float *__restrict__ surv, const int *__restrict__ nsurv,
+                                                           const float *__restrict__ surv, const unsigned *__restrict__ sel, const int *__restrict__ nsel,
                                                            float *__restrict__ raw, int *__restrict__ nraw, unsigned *__restrict__ overflow)
 {
     __shared__ float s_part[SIFT_ORI_WPW][S_BINS][8];
@@ -731,9 +782,10 @@ __global__ __launch_bounds__(64 * SIFT_ORI_WPW) void sift_orient_kernel(const fl
     // image = fastest grid dimension: workgroups in flight together then belong to different images and their
     // atomicAdd(&nraw[img]) go to different addresses (with one image at a time 14 k returning atomics per image queued
     // on a single L2 line: 12 of this kernel's 20 ms)
-    const int img = blockIdx.x, ns = nsurv[img];
-    // waves stride over the survivor list (a grid sized for seed_cap would be millions of empty workgroups)
-    for (int sidx = blockIdx.y * SIFT_ORI_WPW + wv; sidx < ns; sidx += gridDim.y * SIFT_ORI_WPW) {
+    const int img = blockIdx.x, ns = nsel[2 * img];
+    // waves stride over the list of selected survivors (a grid sized for seed_cap would be millions of empty workgroups)
+    for (int si = blockIdx.y * SIFT_ORI_WPW + wv; si < ns; si += gridDim.y * SIFT_ORI_WPW) {
+    const int sidx = (int)sel[(long long)img * dv.seed_cap + si];
     const float *sq = surv + ((long long)img * dv.seed_cap + sidx) * SURV_W;
     const unsigned sd = (unsigned)__float_as_int(sq[0]);
     const int o = sd >> 28, l = (sd >> 26) & 3, r = (sd >> 13) & 0x1FFF, c = sd & 0x1FFF;
@@ -1000,7 +1052,7 @@ __global__ __launch_bounds__(1024) void sift_sort_kernel(const int *__restrict__
 // ---------------------------------------------------------------- finalize
 __global__ __launch_bounds__(256) void sift_finalize_kernel(const float *__restrict__ raw, const int *__restrict__ ncand, SiftDev dv, int pad,
                                                              const unsigned long long *__restrict__ k0, const unsigned long long *__restrict__ k1,
-                                                             const unsigned *__restrict__ sidx, float *__restrict__ fin,
+                                                             const unsigned *__restrict__ sidx, const int *__restrict__ nsel, float *__restrict__ fin,
                                                              float2 *__restrict__ kp_pt, int *__restrict__ kp_count, unsigned *__restrict__ overflow)
 {
     __shared__ unsigned s_hist[256];
@@ -1069,7 +1121,10 @@ __global__ __launch_bounds__(256) void sift_finalize_kernel(const float *__restr
         kp_count[img] = min(offset, dv.kcap);
         // the cap removed keypoints: the reference's SIFT_create() is uncapped (pose_estimator.py:93-94), so its
         // feature set is larger than this one
-        if (dv.nfeatures > 0 && nuniq > dv.nfeatures) atomicOr(&overflow[img], (unsigned)RPE_OVF_SIFT_CAP);
+        const bool cut = nsel[2 * img + 1] != 0;         // sift_select_kernel left weaker survivors without an orientation
+        if (dv.nfeatures > 0 && (nuniq > dv.nfeatures || (cut && nuniq == dv.nfeatures))) atomicOr(&overflow[img], (unsigned)RPE_OVF_SIFT_CAP);
+        // the selected survivors did not fill the cap: keypoints of the ones left out belong to the result and are missing
+        if (cut && nuniq < dv.nfeatures) atomicOr(&overflow[img], (unsigned)RPE_OVF_SIFT_PREFILTER);
         if (offset > dv.kcap) atomicOr(&overflow[img], (unsigned)RPE_OVF_SIFT_KEYPOINTS);
     }
 }
@@ -1365,6 +1420,8 @@ int rpe_sift_create(rpe_handle *h)
     SCHK(hipMalloc(&S->d_nraw, sizeof(int) * NI));
     SCHK(hipMalloc(&S->d_surv, sizeof(float) * NI * dv.seed_cap * SURV_W));
     SCHK(hipMalloc(&S->d_nsurv, sizeof(int) * NI));
+    SCHK(hipMalloc(&S->d_sel, sizeof(unsigned) * NI * dv.seed_cap));
+    SCHK(hipMalloc(&S->d_nsel, sizeof(int) * NI * 2));
     SCHK(hipMalloc(&S->d_overflow, sizeof(int) * NI));
     SCHK(hipMalloc(&S->d_ncand, sizeof(int) * NI));
     SCHK(hipMalloc(&S->d_k0, sizeof(unsigned long long) * NI * S->raw_pad));
@@ -1379,7 +1436,7 @@ void rpe_sift_destroy(rpe_handle *h)
     RpeSiftState *S = h->sift;
     if (!S) return;
     void *p[] = {S->d_gauss, S->d_dog, S->d_tmp, S->d_xtiles, S->d_xmask, S->d_band_cnt, S->d_band_off, S->d_seeds, S->d_nseeds, S->d_raw,
-                 S->d_nraw, S->d_overflow, S->d_ncand, S->d_k0, S->d_k1, S->d_sidx, S->d_fin, S->d_surv, S->d_nsurv};
+                 S->d_nraw, S->d_overflow, S->d_ncand, S->d_k0, S->d_k1, S->d_sidx, S->d_fin, S->d_surv, S->d_nsurv, S->d_sel, S->d_nsel};
     for (void *q : p) if (q) hipFree(q);
     delete S;
     h->sift = nullptr;
@@ -1519,15 +1576,17 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
     hipLaunchKernelGGL(sift_adjust_kernel, dim3(n, (dv.seed_cap + 255) / 256), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
                        (const unsigned *)S->d_seeds, (const int *)S->d_nseeds, S->d_surv, S->d_nsurv);
     MARK(h, RPE_STAGE_HARRIS);
+    hipLaunchKernelGGL(sift_select_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_surv, (const int *)S->d_nsurv, dv,
+                       dv.nfeatures > 0 ? dv.nfeatures + dv.nfeatures / 4 + 256 : 0, S->d_sel, S->d_nsel);
     hipLaunchKernelGGL(sift_orient_kernel, dim3(n, 8192 / SIFT_ORI_WPW), dim3(64 * SIFT_ORI_WPW), 0, h->stream, (const float *)S->d_gauss, dv,
-                       (const float *)S->d_surv, (const int *)S->d_nsurv, S->d_raw, S->d_nraw, h->d_ovf);
+                       (const float *)S->d_surv, (const unsigned *)S->d_sel, (const int *)S->d_nsel, S->d_raw, S->d_nraw, h->d_ovf);
     // 5. sort, dedup, retainBest, compaction
     MARK(h, RPE_STAGE_KEYPOINTS);
     hipLaunchKernelGGL(sift_prefilter_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_raw, (const int *)S->d_nraw, dv, S->raw_pad,
                        S->d_k0, S->d_k1, S->d_sidx, S->d_ncand, h->d_ovf);
     hipLaunchKernelGGL(sift_sort_kernel, dim3(n), dim3(1024), 0, h->stream, (const int *)S->d_ncand, S->raw_pad, S->d_k0, S->d_k1, S->d_sidx);
     hipLaunchKernelGGL(sift_finalize_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_raw, (const int *)S->d_ncand, dv, S->raw_pad,
-                       (const unsigned long long *)S->d_k0, (const unsigned long long *)S->d_k1, (const unsigned *)S->d_sidx,
+                       (const unsigned long long *)S->d_k0, (const unsigned long long *)S->d_k1, (const unsigned *)S->d_sidx, (const int *)S->d_nsel,
                        S->d_fin, h->d_kp_pt, h->d_kp_count, h->d_ovf);
     // 6. descriptors
     MARK(h, RPE_STAGE_ANGLE); MARK(h, RPE_STAGE_BLUR); MARK(h, RPE_STAGE_DESCRIBE);

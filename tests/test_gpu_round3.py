@@ -208,3 +208,24 @@ def test_sift_without_a_cap(oracle):
     assert d["num_matches"] == r["n_matches"] and d["inliers"] == r["inliers"]
     assert np.array_equal(d["R"], r["R"].reshape(3, 3)) and np.array_equal(d["t"].ravel(), r["t"].ravel())
     pe.close()
+
+
+def test_sift_cap_2048_on_a_textured_hd_frame(oracle):
+    """BASELINE configs[2]'s extractor on its own kind of frame: ~10 k refined extrema per image, of which only the
+    nfeatures * 5/4 + 256 strongest get an orientation histogram on the GPU (sift_select_kernel) -- keypoints, their order,
+    descriptors and the cap flag still equal the oracle's, which orients every one of them and cuts afterwards."""
+    from relative_pose_estimation_amd import _capi, synthetic, geometry
+    W, H = 1920, 1080
+    K = geometry.default_camera_matrix(W, H)
+    i1, _, _, _ = synthetic.make_batch(1, K, W, H, cfg=5)
+    e = _capi.Engine(W, H, max_batch=1, nfeatures=2048, max_matches=500, feature_method=_capi.FEATURE_SIFT, norm_type=_capi.NORM_L2)
+    kps, desc, cnt = e.sift_detect_and_compute(i1)
+    ko, do, fo = oracle.sift_detect_and_compute(i1[0], nfeatures=2048, cap=e.kcap, return_flags=True)
+    assert cnt[0] == len(ko) >= 2048, (cnt[0], len(ko))
+    kg = kps[0, :cnt[0]]
+    for f in ("x", "y", "size", "angle", "response"):
+        assert np.array_equal(kg[f].view(np.uint32), ko[f].view(np.uint32)), f
+    assert np.array_equal(kg["octave"], ko["octave"]) and np.array_equal(desc[0, :cnt[0]], do)
+    R, t, inl, nm, st = e.estimate_batch(i1, i1, K)                      # flags of a whole run: the cap removed keypoints
+    assert int(e.fetch_overflow(1)[0]) == _capi.OVF_SIFT_CAP and (fo & _capi.OVF_SIFT_CAP)
+    e.close()
