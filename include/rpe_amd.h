@@ -59,7 +59,7 @@ enum {
     RPE_OVF_ORB_KEYPOINTS  = 1 << 1,   /* more than nfeatures+64 keypoints after the Harris retainBest (ties) */
     RPE_OVF_SIFT_SEEDS     = 1 << 4,   /* more scale-space extrema than base_pixels/16 */
     RPE_OVF_SIFT_RAW       = 1 << 5,   /* more oriented keypoints than the raw list holds */
-    RPE_OVF_SIFT_PREFILTER = 1 << 6,   /* response ties overflowed the pre-sort window, or the strongest refined extrema (the only ones given an orientation under a cap) produced fewer than nfeatures keypoints */
+    RPE_OVF_SIFT_PREFILTER = 1 << 6,   /* response ties overflowed the pre-sort window */
     RPE_OVF_SIFT_CAP       = 1 << 7,   /* the nfeatures cap removed keypoints: differs from the reference's uncapped SIFT_create() (pose_estimator.py:93-94) */
     RPE_OVF_SIFT_KEYPOINTS = 1 << 8    /* more than nfeatures+64 keypoints after retainBest (ties), or more than RPE_SIFT_UNCAPPED_CAPACITY+64 without a cap */
 };

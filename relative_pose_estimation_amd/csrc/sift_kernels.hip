@@ -66,7 +66,8 @@ struct RpeSiftState {
     float *d_raw = nullptr;                                // [img][raw_cap][6]: x y size angle response octave(bits)
     int *d_nraw = nullptr, *d_overflow = nullptr, *d_ncand = nullptr;
     float *d_surv = nullptr; int *d_nsurv = nullptr;        // [img][seed_cap][SURV_W] refined seeds, [img]
-    unsigned *d_sel = nullptr; int *d_nsel = nullptr;       // [img][seed_cap] survivors that get an orientation (sift_select_kernel), [img][2] = {count, cut}
+    unsigned *d_sel = nullptr; int *d_nsel = nullptr;       // [img][seed_cap] survivors that get an orientation (sift_select_kernel), [img][4] = {count, cut, redo, -}
+    int sel_k_override = 0;
     unsigned long long *d_k0 = nullptr, *d_k1 = nullptr; unsigned *d_sidx = nullptr; // sort keys [img][raw_pad]
     int raw_pad = 0;
     int group = 0, group_octaves = 1;                     // image-major schedule (rpe_sift_run): images per group, octaves inside it
@@ -725,12 +726,14 @@ __global__ __launch_bounds__(256) void sift_adjust_kernel(const float *__restric
 // sift_finalize_kernel raises RPE_OVF_SIFT_PREFILTER.  sel_k = 0 (no cap): every survivor is selected.
 __device__ __forceinline__ unsigned s_float_key(float f);
 __global__ __launch_bounds__(256) void sift_select_kernel(const float *__restrict__ surv, const int *__restrict__ nsurv, SiftDev dv, int sel_k,
-                                                           unsigned *__restrict__ sel, int *__restrict__ nsel)
+                                                           unsigned *__restrict__ sel, int *__restrict__ nsel, int *__restrict__ nraw, int redo)
 {
     __shared__ unsigned s_hist[256];
     __shared__ unsigned s_prefix;
     __shared__ int s_kk, s_cnt;
     const int img = blockIdx.x, tid = threadIdx.x;
+    // second round (redo): only the images whose selected survivors did not fill the cap, this time with every survivor
+    if (redo) { if (!nsel[4 * img + 2]) return; sel_k = 0; }
     const int n = min(nsurv[img], dv.seed_cap);
     const float *sv = surv + (long long)img * dv.seed_cap * SURV_W;
     unsigned *out = sel + (long long)img * dv.seed_cap;
@@ -764,7 +767,10 @@ __global__ __launch_bounds__(256) void sift_select_kernel(const float *__restric
     for (int i = tid; i < n; i += 256)
         if (s_float_key(fabsf(sv[(long long)i * SURV_W + 4])) >= thr_key) out[atomicAdd(&s_cnt, 1)] = (unsigned)i;   // order is irrelevant: the keypoints are sorted later
     __syncthreads();
-    if (tid == 0) { nsel[2 * img] = s_cnt; nsel[2 * img + 1] = s_cnt < n ? 1 : 0; }
+    if (tid == 0) {
+        nsel[4 * img] = s_cnt; nsel[4 * img + 1] = s_cnt < n ? 1 : 0;
+        if (!redo) nsel[4 * img + 2] = 0; else nraw[img] = 0;
+    }
 }
 
 // One wave per workgroup: survivors differ in window size (6 to 14+ batches of 64 samples), and a 4-wave workgroup
@@ -773,7 +779,7 @@ __global__ __launch_bounds__(256) void sift_select_kernel(const float *__restric
 #define S_ORI_RMAX1 20      // radius + 1 <= 18: radius = round(4.5 * 1.6 * 2^((l + xi) / 3)), l <= 3, |xi| < 0.5 -> <= 17
 __global__ __launch_bounds__(64 * SIFT_ORI_WPW) void sift_orient_kernel(const float *__restrict__ gauss, SiftDev dv,
                                                            const float *__restrict__ surv, const unsigned *__restrict__ sel, const int *__restrict__ nsel,
-                                                           float *__restrict__ raw, int *__restrict__ nraw, unsigned *__restrict__ overflow)
+                                                           float *__restrict__ raw, int *__restrict__ nraw, unsigned *__restrict__ overflow, int redo)
 {
     __shared__ float s_part[SIFT_ORI_WPW][S_BINS][8];
     __shared__ float s_hist[SIFT_ORI_WPW][S_BINS + 4];
@@ -782,7 +788,8 @@ __global__ __launch_bounds__(64 * SIFT_ORI_WPW) void sift_orient_kernel(const fl
     // image = fastest grid dimension: workgroups in flight together then belong to different images and their
     // atomicAdd(&nraw[img]) go to different addresses (with one image at a time 14 k returning atomics per image queued
     // on a single L2 line: 12 of this kernel's 20 ms)
-    const int img = blockIdx.x, ns = nsel[2 * img];
+    const int img = blockIdx.x, ns = nsel[4 * img];
+    if (redo && !nsel[4 * img + 2]) return;
     // waves stride over the list of selected survivors (a grid sized for seed_cap would be millions of empty workgroups)
     for (int si = blockIdx.y * SIFT_ORI_WPW + wv; si < ns; si += gridDim.y * SIFT_ORI_WPW) {
     const int sidx = (int)sel[(long long)img * dv.seed_cap + si];
@@ -938,12 +945,14 @@ __device__ __forceinline__ unsigned s_float_key(float f)
 // (exact duplicates are rare); otherwise the overflow flag is raised.
 __global__ __launch_bounds__(256) void sift_prefilter_kernel(const float *__restrict__ raw, const int *__restrict__ nraw, SiftDev dv, int pad,
                                                               unsigned long long *__restrict__ k0, unsigned long long *__restrict__ k1,
-                                                              unsigned *__restrict__ sidx, int *__restrict__ ncand, unsigned *__restrict__ overflow)
+                                                              unsigned *__restrict__ sidx, int *__restrict__ ncand, unsigned *__restrict__ overflow,
+                                                              const int *__restrict__ nsel, int redo)
 {
     __shared__ unsigned s_hist[256];
     __shared__ unsigned s_prefix;
     __shared__ int s_kk, s_cnt;
     const int img = blockIdx.x, tid = threadIdx.x;
+    if (redo && !nsel[4 * img + 2]) return;
     const int n = min(nraw[img], dv.raw_cap);
     const float *rw = raw + (long long)img * dv.raw_cap * 6;
     const int K = 2 * dv.nfeatures + 1024;
@@ -998,11 +1007,12 @@ __global__ __launch_bounds__(256) void sift_prefilter_kernel(const float *__rest
 #define SORT_C 2048
 __global__ __launch_bounds__(1024) void sift_sort_kernel(const int *__restrict__ ncand, int pad,
                                                           unsigned long long *__restrict__ k0, unsigned long long *__restrict__ k1,
-                                                          unsigned *__restrict__ sidx)
+                                                          unsigned *__restrict__ sidx, const int *__restrict__ nsel, int redo)
 {
     __shared__ unsigned long long s0[SORT_C], s1[SORT_C];
     __shared__ unsigned si[SORT_C];
     const int img = blockIdx.x, tid = threadIdx.x;
+    if (redo && !nsel[4 * img + 2]) return;
     const int n = ncand[img];
     int P = 64;
     while (P < n) P <<= 1;
@@ -1052,7 +1062,7 @@ __global__ __launch_bounds__(1024) void sift_sort_kernel(const int *__restrict__
 // ---------------------------------------------------------------- finalize
 __global__ __launch_bounds__(256) void sift_finalize_kernel(const float *__restrict__ raw, const int *__restrict__ ncand, SiftDev dv, int pad,
                                                              const unsigned long long *__restrict__ k0, const unsigned long long *__restrict__ k1,
-                                                             const unsigned *__restrict__ sidx, const int *__restrict__ nsel, float *__restrict__ fin,
+                                                             const unsigned *__restrict__ sidx, int *__restrict__ nsel, int redo, float *__restrict__ fin,
                                                              float2 *__restrict__ kp_pt, int *__restrict__ kp_count, unsigned *__restrict__ overflow)
 {
     __shared__ unsigned s_hist[256];
@@ -1060,6 +1070,7 @@ __global__ __launch_bounds__(256) void sift_finalize_kernel(const float *__restr
     __shared__ unsigned s_prefix;
     __shared__ int s_kk, s_nuniq;
     const int img = blockIdx.x, tid = threadIdx.x;
+    if (redo && !nsel[4 * img + 2]) return;
     const int n = ncand[img];
     const unsigned long long *a0 = k0 + (long long)img * pad, *a1 = k1 + (long long)img * pad;
     const unsigned *ix = sidx + (long long)img * pad;
@@ -1073,6 +1084,13 @@ __global__ __launch_bounds__(256) void sift_finalize_kernel(const float *__restr
     atomicAdd(&s_nuniq, cnt);
     __syncthreads();
     const int nuniq = s_nuniq;
+    const bool cut = nsel[4 * img + 1] != 0;             // sift_select_kernel left weaker survivors without an orientation
+    if (cut && nuniq < dv.nfeatures) {
+        // the selected survivors did not fill the cap: keypoints of the ones left out belong to the result.  Nothing is
+        // written; the second round orients every survivor of this image and comes back here with cut = 0
+        if (tid == 0) nsel[4 * img + 2] = 1;
+        return;
+    }
     unsigned thr_key = 0;
     if (dv.nfeatures > 0 && nuniq > dv.nfeatures) {       // retainBest: response >= the nfeatures-th best
         unsigned prefix = 0, mask = 0;
@@ -1121,10 +1139,7 @@ __global__ __launch_bounds__(256) void sift_finalize_kernel(const float *__restr
         kp_count[img] = min(offset, dv.kcap);
         // the cap removed keypoints: the reference's SIFT_create() is uncapped (pose_estimator.py:93-94), so its
         // feature set is larger than this one
-        const bool cut = nsel[2 * img + 1] != 0;         // sift_select_kernel left weaker survivors without an orientation
-        if (dv.nfeatures > 0 && (nuniq > dv.nfeatures || (cut && nuniq == dv.nfeatures))) atomicOr(&overflow[img], (unsigned)RPE_OVF_SIFT_CAP);
-        // the selected survivors did not fill the cap: keypoints of the ones left out belong to the result and are missing
-        if (cut && nuniq < dv.nfeatures) atomicOr(&overflow[img], (unsigned)RPE_OVF_SIFT_PREFILTER);
+        if (dv.nfeatures > 0 && (nuniq > dv.nfeatures || cut)) atomicOr(&overflow[img], (unsigned)RPE_OVF_SIFT_CAP);
         if (offset > dv.kcap) atomicOr(&overflow[img], (unsigned)RPE_OVF_SIFT_KEYPOINTS);
     }
 }
@@ -1421,7 +1436,8 @@ int rpe_sift_create(rpe_handle *h)
     SCHK(hipMalloc(&S->d_surv, sizeof(float) * NI * dv.seed_cap * SURV_W));
     SCHK(hipMalloc(&S->d_nsurv, sizeof(int) * NI));
     SCHK(hipMalloc(&S->d_sel, sizeof(unsigned) * NI * dv.seed_cap));
-    SCHK(hipMalloc(&S->d_nsel, sizeof(int) * NI * 2));
+    SCHK(hipMalloc(&S->d_nsel, sizeof(int) * NI * 4));
+    if (const char *e = getenv("RPE_SIFT_SEL_K")) S->sel_k_override = atoi(e);      // tests: a small value forces the second round
     SCHK(hipMalloc(&S->d_overflow, sizeof(int) * NI));
     SCHK(hipMalloc(&S->d_ncand, sizeof(int) * NI));
     SCHK(hipMalloc(&S->d_k0, sizeof(unsigned long long) * NI * S->raw_pad));
@@ -1576,18 +1592,23 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
     hipLaunchKernelGGL(sift_adjust_kernel, dim3(n, (dv.seed_cap + 255) / 256), dim3(256), 0, h->stream, (const float *)S->d_gauss, dv,
                        (const unsigned *)S->d_seeds, (const int *)S->d_nseeds, S->d_surv, S->d_nsurv);
     MARK(h, RPE_STAGE_HARRIS);
-    hipLaunchKernelGGL(sift_select_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_surv, (const int *)S->d_nsurv, dv,
-                       dv.nfeatures > 0 ? dv.nfeatures + dv.nfeatures / 4 + 256 : 0, S->d_sel, S->d_nsel);
-    hipLaunchKernelGGL(sift_orient_kernel, dim3(n, 8192 / SIFT_ORI_WPW), dim3(64 * SIFT_ORI_WPW), 0, h->stream, (const float *)S->d_gauss, dv,
-                       (const float *)S->d_surv, (const unsigned *)S->d_sel, (const int *)S->d_nsel, S->d_raw, S->d_nraw, h->d_ovf);
-    // 5. sort, dedup, retainBest, compaction
-    MARK(h, RPE_STAGE_KEYPOINTS);
-    hipLaunchKernelGGL(sift_prefilter_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_raw, (const int *)S->d_nraw, dv, S->raw_pad,
-                       S->d_k0, S->d_k1, S->d_sidx, S->d_ncand, h->d_ovf);
-    hipLaunchKernelGGL(sift_sort_kernel, dim3(n), dim3(1024), 0, h->stream, (const int *)S->d_ncand, S->raw_pad, S->d_k0, S->d_k1, S->d_sidx);
-    hipLaunchKernelGGL(sift_finalize_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_raw, (const int *)S->d_ncand, dv, S->raw_pad,
-                       (const unsigned long long *)S->d_k0, (const unsigned long long *)S->d_k1, (const unsigned *)S->d_sidx, (const int *)S->d_nsel,
-                       S->d_fin, h->d_kp_pt, h->d_kp_count, h->d_ovf);
+    // 5. orientation of the strongest survivors, sort, dedup, retainBest, compaction.  Round 1 only does something for images
+    //    whose selected survivors did not fill the cap (sift_finalize_kernel marked them): every survivor is oriented then.
+    const int sel_k = dv.nfeatures > 0 ? (S->sel_k_override > 0 ? S->sel_k_override : dv.nfeatures + dv.nfeatures / 4 + 256) : 0;
+    for (int redo = 0; redo < (sel_k > 0 ? 2 : 1); ++redo) {
+        hipLaunchKernelGGL(sift_select_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_surv, (const int *)S->d_nsurv, dv,
+                           sel_k, S->d_sel, S->d_nsel, S->d_nraw, redo);
+        hipLaunchKernelGGL(sift_orient_kernel, dim3(n, (redo ? 64 : 8192) / SIFT_ORI_WPW), dim3(64 * SIFT_ORI_WPW), 0, h->stream, (const float *)S->d_gauss, dv,
+                           (const float *)S->d_surv, (const unsigned *)S->d_sel, (const int *)S->d_nsel, S->d_raw, S->d_nraw, h->d_ovf, redo);
+        if (!redo) MARK(h, RPE_STAGE_KEYPOINTS);
+        hipLaunchKernelGGL(sift_prefilter_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_raw, (const int *)S->d_nraw, dv, S->raw_pad,
+                           S->d_k0, S->d_k1, S->d_sidx, S->d_ncand, h->d_ovf, (const int *)S->d_nsel, redo);
+        hipLaunchKernelGGL(sift_sort_kernel, dim3(n), dim3(1024), 0, h->stream, (const int *)S->d_ncand, S->raw_pad, S->d_k0, S->d_k1, S->d_sidx,
+                           (const int *)S->d_nsel, redo);
+        hipLaunchKernelGGL(sift_finalize_kernel, dim3(n), dim3(256), 0, h->stream, (const float *)S->d_raw, (const int *)S->d_ncand, dv, S->raw_pad,
+                           (const unsigned long long *)S->d_k0, (const unsigned long long *)S->d_k1, (const unsigned *)S->d_sidx, S->d_nsel, redo,
+                           S->d_fin, h->d_kp_pt, h->d_kp_count, h->d_ovf);
+    }
     // 6. descriptors
     MARK(h, RPE_STAGE_ANGLE); MARK(h, RPE_STAGE_BLUR); MARK(h, RPE_STAGE_DESCRIBE);
     hipLaunchKernelGGL(sift_describe_kernel, dim3((dv.kcap + SIFT_DESC_KPW - 1) / SIFT_DESC_KPW, n), dim3(64 * SIFT_DESC_KPW), 0, h->stream, (const float *)S->d_gauss, dv,

@@ -229,3 +229,31 @@ def test_sift_cap_2048_on_a_textured_hd_frame(oracle):
     R, t, inl, nm, st = e.estimate_batch(i1, i1, K)                      # flags of a whole run: the cap removed keypoints
     assert int(e.fetch_overflow(1)[0]) == _capi.OVF_SIFT_CAP and (fo & _capi.OVF_SIFT_CAP)
     e.close()
+
+
+def test_sift_second_round_when_the_strongest_do_not_fill_the_cap(oracle, monkeypatch):
+    """The survivor selection is exact only while the selected ones produce >= nfeatures unique keypoints; when they do not,
+    the image is oriented again with every survivor.  RPE_SIFT_SEL_K = 40 (instead of nfeatures * 5/4 + 256) forces that on
+    ordinary images: keypoints, descriptors, flags and pose still equal the oracle's."""
+    from relative_pose_estimation_amd import _capi, synthetic, geometry
+    K = geometry.default_camera_matrix(320, 240)
+    i1, i2, _, _ = synthetic.make_batch(2, K, 320, 240, cfg=6)
+    monkeypatch.setenv("RPE_SIFT_SEL_K", "40")
+    e = _capi.Engine(320, 240, max_batch=2, nfeatures=300, max_matches=200, feature_method=_capi.FEATURE_SIFT, norm_type=_capi.NORM_L2)
+    monkeypatch.delenv("RPE_SIFT_SEL_K")
+    imgs = np.concatenate([i1, i2])
+    kps, desc, cnt = e.sift_detect_and_compute(imgs)
+    for n in range(len(imgs)):
+        ko, do = oracle.sift_detect_and_compute(imgs[n], nfeatures=300, cap=e.kcap)
+        assert cnt[n] == len(ko) >= 300, (n, cnt[n], len(ko))
+        kg = kps[n, :cnt[n]]
+        for f in ("x", "y", "size", "angle", "response"):
+            assert np.array_equal(kg[f].view(np.uint32), ko[f].view(np.uint32)), (n, f)
+        assert np.array_equal(desc[n, :cnt[n]], do)
+    R, t, inl, nm, st = e.estimate_batch(i1, i2, K)
+    ovf = e.fetch_overflow(2)
+    for n in range(2):
+        r = oracle.estimate_pose_batch(i1[n:n + 1], i2[n:n + 1], K, 300, 200, nthreads=1, method="SIFT")[0]
+        assert st[n] == r["status"] and nm[n] == r["n_matches"] and inl[n] == r["inliers"] and np.array_equal(R[n], r["R"].reshape(3, 3))
+        assert int(ovf[n]) == int(r["overflow"])
+    e.close()
