@@ -72,6 +72,7 @@ struct RpeSiftState {
     int raw_pad = 0;
     int group = 0, group_octaves = 1;                     // image-major schedule (rpe_sift_run): images per group, octaves inside it
     bool fused_all = false;                                // every blur radius has a fused instantiation
+    bool march = false;                                    // levels 1-3 / 4-5 of the large octaves by sift_march_kernel
     int xtile_oct_end[12] = {0};                           // tiles of octaves 0 .. o end here in d_xtiles
     int ks[6] = {0, 0, 0, 0, 0, 0};                      // tap counts of c_skern
     float *d_fin = nullptr;                                // [img][kcap][6] un-halved keypoints in sorted order
@@ -408,6 +409,175 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------ marching pyramid
+// NL consecutive levels of one octave in ONE pass over the source level: a workgroup owns a strip of MARCH_SW columns and
+// marches down the image 8 rows per step.  Level j keeps a ring of its last 2 R_j + 8 row-filtered rows in LDS; its column
+// filter produces the 8 rows that lie R_j rows above the newest one, which are stored and are at once the source rows of
+// level j + 1's row filter.  The source level is read once (the tile kernels read every level back), every row filter runs
+// once per row (the 32-row tiles ran it on 32 + 2R rows), and there are no window loads.
+// Arithmetic and its order are those of sift_blur_fused_kernel, bit for bit.  Borders: the column filter adds its taps as
+// symmetric pairs, so running the march over a source extended by reflect-101 above and below (P = sum of the radii rows)
+// yields every level's own reflect-101 extension exactly -- no special rows.  The row filter accumulates left to right and
+// is not symmetric: at the image's left / right edge a level's out-of-image columns are written as copies of its mirror
+// columns (the column-filter lane of such a column reads the ring at the mirrored column).
+#define MARCH_SW 128
+template <int NL, int R0, int R1, int R2>
+struct MarchGeo {
+    static constexpr int R(int j) { return j == 0 ? R0 : j == 1 ? R1 : R2; }
+    static constexpr int P = R0 + R1 + (NL > 2 ? R2 : 0);
+    static constexpr int H(int j) { int a = 0; for (int m = j + 1; m < NL; ++m) a += R(m); return a; }     // halo columns of level j on either side
+    static constexpr int L(int j) { int a = 0; for (int m = 0; m <= j; ++m) a += R(m); return a; }         // rows level j lags behind the source
+    static constexpr int W(int j) { return MARCH_SW + 2 * H(j); }
+    static constexpr int NG(int j) { return (W(j) + 7) / 8; }
+    static constexpr int SRCW(int j) { return 8 * NG(j) + 2 * R(j); }      // columns of level j's source rows that are read
+    static constexpr int SS(int j) { return SRCW(j) | 1; }
+    static constexpr int TS(int j) { return (8 * NG(j)) | 1; }
+    static constexpr int D(int j) { return 2 * R(j) + 8; }
+    static constexpr int OFF_SRC(int j) { int a = 0; for (int m = 0; m < j; ++m) a += 8 * SS(m) + D(m) * TS(m); return a; }
+    static constexpr int OFF_T(int j) { return OFF_SRC(j) + 8 * SS(j); }
+    static constexpr int TOTAL = OFF_SRC(NL);
+};
+
+template <class G, int J>
+__device__ __forceinline__ void march_rowfilter(float *lds, int kid, int tid)
+{
+    constexpr int R = G::R(J), KS = 2 * R + 1, NGJ = G::NG(J), SSJ = G::SS(J), TSJ = G::TS(J);
+    float k[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) k[i] = c_skern[kid][i];
+    const float *srcb = lds + G::OFF_SRC(J);
+    float *win = lds + G::OFF_T(J) + 2 * R * TSJ;              // the 8 new rows go behind the 2R rows carried over
+    for (int it = tid; it < ((NGJ + 7) / 8) * 64; it += 256) {
+        const int r = (it >> 2) & 7, g = 8 * (it >> 6) + (((it >> 3) & 4) | (it & 3));
+        if (g >= NGJ) continue;
+        f32x2 P[4 + 2 * R];
+        lds_pairs<false>(P, lds_addr(srcb + r * SSJ + 8 * g), std::make_integer_sequence<int, 4 + 2 * R>());
+        float *o = win + r * TSJ + 8 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x2 acc = f32x2{k[0], k[0]} * P[j];
+#pragma unroll
+            for (int i = 1; i < KS; ++i) { const f32x2 kk = {k[i], k[i]}; acc = __builtin_elementwise_fma(kk, P[j + i], acc); }
+            o[j] = acc.x;
+            o[j + 4] = acc.y;
+        }
+    }
+}
+
+template <class G, int J, int NL>
+__device__ __forceinline__ void march_colfilter(float *lds, int kid, int tid, int s, int x0, int w, int h, float *__restrict__ plane,
+                                                float *__restrict__ decp, int w2, int h2)
+{
+    constexpr int R = G::R(J), WJ = G::W(J), HJ = G::H(J), TSJ = G::TS(J);
+    const int c = x0 - HJ + tid;                                  // absolute column of this lane
+    if (tid >= WJ || c < 0 || c >= w) return;                     // out-of-image columns are written by the lane of their mirror column
+    float k[R + 1];
+#pragma unroll
+    for (int i = 0; i <= R; ++i) k[i] = c_skern[kid][R + i];
+    // the window of this column: rows 0 .. 2R-1 carried over from the previous step, rows 2R .. 2R+7 new; static addresses
+    float *win = lds + G::OFF_T(J) + tid;
+    f32x2 P[4 + 2 * R];
+#pragma unroll
+    for (int i = 0; i < 4 + 2 * R; ++i) P[i] = f32x2{win[i * TSJ], win[(i + 4) * TSJ]};
+    // the last 2R rows move up for the next step (this lane is the only one that touches its column)
+#pragma unroll
+    for (int i = 0; i < 2 * R; ++i) win[i * TSJ] = i + 8 < 4 + 2 * R ? P[i + 8].x : P[i + 4].y;
+    f32x2 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        acc[j] = f32x2{k[0], k[0]} * P[j + R];
+#pragma unroll
+        for (int t = 1; t <= R; ++t) { const f32x2 kk = {k[t], k[t]}; acc[j] = __builtin_elementwise_fma(kk, P[j + R + t] + P[j + R - t], acc[j]); }
+    }
+    if constexpr (J + 1 < NL) {                                   // source rows of the next level (this level's column range)
+        constexpr int SSN = G::SS(J + 1 < NL ? J + 1 : J);
+        float *nb = lds + G::OFF_SRC(J + 1 < NL ? J + 1 : J);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { nb[j * SSN + tid] = acc[j].x; nb[(j + 4) * SSN + tid] = acc[j].y; }
+        // reflect-101 of this level at the image's left / right edge: the mirror columns inside the strip's range
+        const int ml = -c - (x0 - HJ), mr = 2 * (w - 1) - c - (x0 - HJ);
+        if (c > 0 && ml >= 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { nb[j * SSN + ml] = acc[j].x; nb[(j + 4) * SSN + ml] = acc[j].y; }
+        }
+        if (c < w - 1 && mr < WJ) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { nb[j * SSN + mr] = acc[j].x; nb[(j + 4) * SSN + mr] = acc[j].y; }
+        }
+    }
+    const int y0 = -G::P + 8 * s - G::L(J);                       // first of the 8 rows produced in this step
+    if (tid >= HJ && tid < HJ + MARCH_SW && y0 + 7 >= 0 && y0 < h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int y = y0 + j + 4 * hh;
+                const float v = hh ? acc[j].y : acc[j].x;
+                if (y >= 0 && y < h) {
+                    plane[(size_t)y * w + c] = v;
+                    if (decp && !(y & 1) && !(c & 1) && (y >> 1) < h2 && (c >> 1) < w2) decp[(size_t)(y >> 1) * w2 + (c >> 1)] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int NL, int R0, int R1, int R2>
+__global__ __launch_bounds__(256) void sift_march_kernel(const float *__restrict__ src, long long sstride, float *__restrict__ dst, long long dstride,
+                                                          long long pn, int w, int h, int kid0, float *__restrict__ dec, int dec_level, int w2, int h2)
+{
+    typedef MarchGeo<NL, R0, R1, R2> G;
+    __shared__ __attribute__((aligned(16))) float lds[G::TOTAL];
+    const int tid = threadIdx.x, x0 = blockIdx.x * MARCH_SW;
+    const float *s = src + (long long)blockIdx.y * sstride;
+    float *d = dst + (long long)blockIdx.y * dstride;
+    float *decp = dec ? dec + (long long)blockIdx.y * dstride : nullptr;
+    // this lane's share of the 8 x SRCW(0) source values of a step: fixed (row, column) slots, only the row base moves
+    constexpr int SW0 = G::SRCW(0), NLD = (8 * SW0 + 255) / 256;
+    int lrow[NLD], lcol[NLD], loff[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int idx = min(tid + 256 * q, 8 * SW0 - 1);
+        const int r = idx / SW0, cc = idx - r * SW0;
+        int c = x0 - G::P + cc;
+        c = c < 0 ? -c : c; c = c >= w ? 2 * w - 2 - c : c; c = min(max(c, 0), w - 1);
+        lrow[q] = r; lcol[q] = c; loff[q] = r * G::SS(0) + cc;
+    }
+    float stage[NLD];
+    auto fetch = [&](int step) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            int y = -G::P + 8 * step + lrow[q];
+            y = y < 0 ? -y : y; y = y >= h ? 2 * h - 2 - y : y; y = min(max(y, 0), h - 1);
+            stage[q] = s[(size_t)y * w + lcol[q]];
+        }
+    };
+    const int nsteps = (h + 2 * G::P + 7) / 8;
+    fetch(0);
+    for (int st = 0; st < nsteps; ++st) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) lds[G::OFF_SRC(0) + loff[q]] = stage[q];      // (the clamped duplicates of the last slot rewrite the same value)
+        __syncthreads();
+        if (st + 1 < nsteps) fetch(st + 1);                      // next step's rows fly during this step's arithmetic
+        march_rowfilter<G, 0>(lds, kid0, tid);
+        __syncthreads();
+        march_colfilter<G, 0, NL>(lds, kid0, tid, st, x0, w, h, d, dec_level == 0 ? decp : nullptr, w2, h2);
+        if constexpr (NL > 1) {
+            __syncthreads();
+            march_rowfilter<G, (NL > 1 ? 1 : 0)>(lds, kid0 + 1, tid);
+            __syncthreads();
+            march_colfilter<G, (NL > 1 ? 1 : 0), NL>(lds, kid0 + 1, tid, st, x0, w, h, d + pn, dec_level == 1 ? decp : nullptr, w2, h2);
+        }
+        if constexpr (NL > 2) {
+            __syncthreads();
+            march_rowfilter<G, (NL > 2 ? 2 : 0)>(lds, kid0 + 2, tid);
+            __syncthreads();
+            march_colfilter<G, (NL > 2 ? 2 : 0), NL>(lds, kid0 + 2, tid, st, x0, w, h, d + 2 * pn, dec_level == 2 ? decp : nullptr, w2, h2);
+        }
+        __syncthreads();
     }
 }
 
@@ -1424,6 +1594,7 @@ int rpe_sift_create(rpe_handle *h)
         for (int i = 0; i < S_NG; ++i) { const int r = ks[i] >> 1; if (r != 5 && r != 6 && r != 8 && r != 10 && r != 13) need_tmp = true; }
         if (need_tmp) SCHK(hipMalloc(&S->d_tmp, sizeof(float) * NI * dv.tstride * 2));
         S->fused_all = !need_tmp;
+        S->march = getenv("RPE_SIFT_MARCH") && (ks[1] >> 1) == 5 && (ks[2] >> 1) == 6 && (ks[3] >> 1) == 8 && (ks[4] >> 1) == 10 && (ks[5] >> 1) == 13;
         if (const char *e = getenv("RPE_SIFT_GROUP")) S->group = atoi(e);
         if (const char *e = getenv("RPE_SIFT_GROUP_OCTAVES")) S->group_octaves = atoi(e) > 0 ? atoi(e) : 1;
     }
@@ -1546,6 +1717,18 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
                                    (const float *)(G + dv.goff[o - 1] + (long long)S_NOL * dv.w[o - 1] * dv.h[o - 1]),
                                    G + dv.goff[o], dv.gstride, dv.w[o - 1], w, hh);
             have_l0 = false;
+            if (S->march && w >= 256 && hh >= 64) {
+                // levels 1-3 in one march over level 0 (+ level 0 of the next octave), levels 4-5 in one march over level 3
+                const bool last = o + 1 >= dv.noct;
+                float *dec = !last ? G + dv.goff[o + 1] : nullptr;
+                const dim3 grid((w + MARCH_SW - 1) / MARCH_SW, g);
+                hipLaunchKernelGGL((sift_march_kernel<3, 5, 6, 8>), grid, dim3(256), 0, h->stream, (const float *)(G + dv.goff[o]), dv.gstride,
+                                   G + dv.goff[o] + pn, dv.gstride, pn, w, hh, 1, dec, 2, last ? 0 : dv.w[o + 1], last ? 0 : dv.h[o + 1]);
+                hipLaunchKernelGGL((sift_march_kernel<2, 10, 13, 0>), grid, dim3(256), 0, h->stream, (const float *)(G + dv.goff[o] + 3 * pn), dv.gstride,
+                                   G + dv.goff[o] + 4 * pn, dv.gstride, pn, w, hh, 4, (float *)nullptr, -1, 0, 0);
+                have_l0 = !last;
+                continue;
+            }
             for (int i = 1; i < S_NG; ++i) {
                 const bool last = o + 1 >= dv.noct;
                 float *dec = i == S_NOL && !last ? G + dv.goff[o + 1] : nullptr;
