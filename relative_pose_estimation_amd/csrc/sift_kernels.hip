@@ -424,6 +424,24 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
 // is not symmetric: at the image's left / right edge a level's out-of-image columns are written as copies of its mirror
 // columns (the column-filter lane of such a column reads the ring at the mirrored column).
 #define MARCH_SW 128
+// (lds[addr + 4 TS i], lds[addr + 4 TS (i + 4)]) for every i of the sequence: each half is its own ds_read_b32 at a static
+// offset, so it lands in its half of the register pair (left to the compiler the two uses of a value share one load and
+// ~100 v_mov per step rebuild the packed operands)
+template <int TS, int I>
+__device__ __forceinline__ void lds_colpair(f32x2 &p, unsigned addr)
+{
+    float a, b;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(a) : "v"(addr), "n"(4 * TS * I) : "memory");
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(b) : "v"(addr), "n"(4 * TS * (I + 4)) : "memory");
+    p = f32x2{a, b};
+}
+template <int TS, int... Is>
+__device__ __forceinline__ void lds_colpairs(f32x2 *P, unsigned addr, std::integer_sequence<int, Is...>)
+{
+    (lds_colpair<TS, Is>(P[Is], addr), ...);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    (asm_pin(P[Is]), ...);
+}
 template <int NL, int R0, int R1, int R2>
 struct MarchGeo {
     static constexpr int R(int j) { return j == 0 ? R0 : j == 1 ? R1 : R2; }
@@ -480,8 +498,7 @@ __device__ __forceinline__ void march_colfilter(float *lds, int kid, int tid, in
     // the window of this column: rows 0 .. 2R-1 carried over from the previous step, rows 2R .. 2R+7 new; static addresses
     float *win = lds + G::OFF_T(J) + tid;
     f32x2 P[4 + 2 * R];
-#pragma unroll
-    for (int i = 0; i < 4 + 2 * R; ++i) P[i] = f32x2{win[i * TSJ], win[(i + 4) * TSJ]};
+    lds_colpairs<TSJ>(P, lds_addr(win), std::make_integer_sequence<int, 4 + 2 * R>());
     // the last 2R rows move up for the next step (this lane is the only one that touches its column)
 #pragma unroll
     for (int i = 0; i < 2 * R; ++i) win[i * TSJ] = i + 8 < 4 + 2 * R ? P[i + 8].x : P[i + 4].y;
@@ -510,6 +527,7 @@ __device__ __forceinline__ void march_colfilter(float *lds, int kid, int tid, in
     }
     const int y0 = -G::P + 8 * s - G::L(J);                       // first of the 8 rows produced in this step
     if (tid >= HJ && tid < HJ + MARCH_SW && y0 + 7 >= 0 && y0 < h) {
+        const unsigned voff = (unsigned)c * 4u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -517,7 +535,8 @@ __device__ __forceinline__ void march_colfilter(float *lds, int kid, int tid, in
                 const int y = y0 + j + 4 * hh;
                 const float v = hh ? acc[j].y : acc[j].x;
                 if (y >= 0 && y < h) {
-                    plane[(size_t)y * w + c] = v;
+                    // scalar row base + 32-bit lane offset: no 64-bit address arithmetic per store
+                    asm volatile("global_store_dword %0, %1, %2" :: "v"(voff), "v"(v), "s"(plane + (size_t)y * w) : "memory");
                     if (decp && !(y & 1) && !(c & 1) && (y >> 1) < h2 && (c >> 1) < w2) decp[(size_t)(y >> 1) * w2 + (c >> 1)] = v;
                 }
             }

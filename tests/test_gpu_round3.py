@@ -257,3 +257,24 @@ def test_sift_second_round_when_the_strongest_do_not_fill_the_cap(oracle, monkey
         assert st[n] == r["status"] and nm[n] == r["n_matches"] and inl[n] == r["inliers"] and np.array_equal(R[n], r["R"].reshape(3, 3))
         assert int(ovf[n]) == int(r["overflow"])
     e.close()
+
+
+def test_marching_pyramid_is_bit_identical(oracle, monkeypatch):
+    """RPE_SIFT_MARCH=1 builds levels 1-3 and 4-5 of the large octaves with sift_march_kernel (one pass over the source level
+    each, rings of row-filtered rows in LDS) instead of one tile kernel launch per level: the whole Gaussian pyramid, the
+    keypoints and the descriptors must not change by a bit (640x480 and 320x240 octaves march here, the rest take the tiles)."""
+    from relative_pose_estimation_amd import _capi, synthetic, geometry
+    K = geometry.default_camera_matrix(320, 240)
+    i1, i2, _, _ = synthetic.make_batch(1, K, 320, 240, cfg=6)
+    imgs = np.concatenate([i1, i2])
+    monkeypatch.setenv("RPE_SIFT_MARCH", "1")
+    e = _capi.Engine(320, 240, max_batch=1, nfeatures=600, max_matches=300, feature_method=_capi.FEATURE_SIFT, norm_type=_capi.NORM_L2)
+    monkeypatch.delenv("RPE_SIFT_MARCH")
+    kps, desc, cnt = e.sift_detect_and_compute(imgs)
+    for n in range(2):
+        go, dims = oracle.sift_gauss_pyramid(imgs[n])
+        gg = e.sift_debug_gauss(n)
+        assert gg.shape == go.shape and np.array_equal(gg.view(np.uint32), go.view(np.uint32)), "gaussian pyramid differs"
+        ko, do = oracle.sift_detect_and_compute(imgs[n], nfeatures=600, cap=e.kcap)
+        assert cnt[n] == len(ko) and np.array_equal(desc[n, :cnt[n]], do)
+    e.close()
