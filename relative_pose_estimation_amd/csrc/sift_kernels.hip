@@ -423,7 +423,10 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
 // yields every level's own reflect-101 extension exactly -- no special rows.  The row filter accumulates left to right and
 // is not symmetric: at the image's left / right edge a level's out-of-image columns are written as copies of its mirror
 // columns (the column-filter lane of such a column reads the ring at the mirrored column).
+#ifndef MARCH_SW
 #define MARCH_SW 128
+#endif
+#define MARCH_NT (MARCH_SW >= 128 ? 256 : 128)     // threads per workgroup: one lane per column of the widest level
 // (lds[addr + 4 TS i], lds[addr + 4 TS (i + 4)]) for every i of the sequence: each half is its own ds_read_b32 at a static
 // offset, so it lands in its half of the register pair (left to the compiler the two uses of a value share one load and
 // ~100 v_mov per step rebuild the packed operands)
@@ -468,7 +471,7 @@ __device__ __forceinline__ void march_rowfilter(float *lds, int kid, int tid)
     for (int i = 0; i < KS; ++i) k[i] = c_skern[kid][i];
     const float *srcb = lds + G::OFF_SRC(J);
     float *win = lds + G::OFF_T(J) + 2 * R * TSJ;              // the 8 new rows go behind the 2R rows carried over
-    for (int it = tid; it < ((NGJ + 7) / 8) * 64; it += 256) {
+    for (int it = tid; it < ((NGJ + 7) / 8) * 64; it += MARCH_NT) {
         const int r = (it >> 2) & 7, g = 8 * (it >> 6) + (((it >> 3) & 4) | (it & 3));
         if (g >= NGJ) continue;
         f32x2 P[4 + 2 * R];
@@ -545,7 +548,7 @@ __device__ __forceinline__ void march_colfilter(float *lds, int kid, int tid, in
 }
 
 template <int NL, int R0, int R1, int R2>
-__global__ __launch_bounds__(256) void sift_march_kernel(const float *__restrict__ src, long long sstride, float *__restrict__ dst, long long dstride,
+__global__ __launch_bounds__(MARCH_NT) void sift_march_kernel(const float *__restrict__ src, long long sstride, float *__restrict__ dst, long long dstride,
                                                           long long pn, int w, int h, int kid0, float *__restrict__ dec, int dec_level, int w2, int h2)
 {
     typedef MarchGeo<NL, R0, R1, R2> G;
@@ -555,11 +558,12 @@ __global__ __launch_bounds__(256) void sift_march_kernel(const float *__restrict
     float *d = dst + (long long)blockIdx.y * dstride;
     float *decp = dec ? dec + (long long)blockIdx.y * dstride : nullptr;
     // this lane's share of the 8 x SRCW(0) source values of a step: fixed (row, column) slots, only the row base moves
-    constexpr int SW0 = G::SRCW(0), NLD = (8 * SW0 + 255) / 256;
+    constexpr int SW0 = G::SRCW(0), NLD = (8 * SW0 + MARCH_NT - 1) / MARCH_NT;
+    static_assert(G::W(0) <= MARCH_NT, "one lane per column");
     int lrow[NLD], lcol[NLD], loff[NLD];
 #pragma unroll
     for (int q = 0; q < NLD; ++q) {
-        const int idx = min(tid + 256 * q, 8 * SW0 - 1);
+        const int idx = min(tid + MARCH_NT * q, 8 * SW0 - 1);
         const int r = idx / SW0, cc = idx - r * SW0;
         int c = x0 - G::P + cc;
         c = c < 0 ? -c : c; c = c >= w ? 2 * w - 2 - c : c; c = min(max(c, 0), w - 1);
@@ -1741,9 +1745,9 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
                 const bool last = o + 1 >= dv.noct;
                 float *dec = !last ? G + dv.goff[o + 1] : nullptr;
                 const dim3 grid((w + MARCH_SW - 1) / MARCH_SW, g);
-                hipLaunchKernelGGL((sift_march_kernel<3, 5, 6, 8>), grid, dim3(256), 0, h->stream, (const float *)(G + dv.goff[o]), dv.gstride,
+                hipLaunchKernelGGL((sift_march_kernel<3, 5, 6, 8>), grid, dim3(MARCH_NT), 0, h->stream, (const float *)(G + dv.goff[o]), dv.gstride,
                                    G + dv.goff[o] + pn, dv.gstride, pn, w, hh, 1, dec, 2, last ? 0 : dv.w[o + 1], last ? 0 : dv.h[o + 1]);
-                hipLaunchKernelGGL((sift_march_kernel<2, 10, 13, 0>), grid, dim3(256), 0, h->stream, (const float *)(G + dv.goff[o] + 3 * pn), dv.gstride,
+                hipLaunchKernelGGL((sift_march_kernel<2, 10, 13, 0>), grid, dim3(MARCH_NT), 0, h->stream, (const float *)(G + dv.goff[o] + 3 * pn), dv.gstride,
                                    G + dv.goff[o] + 4 * pn, dv.gstride, pn, w, hh, 4, (float *)nullptr, -1, 0, 0);
                 have_l0 = !last;
                 continue;
