@@ -460,6 +460,10 @@ struct MarchGeo {
     static constexpr int OFF_SRC(int j) { int a = 0; for (int m = 0; m < j; ++m) a += 8 * SS(m) + D(m) * TS(m); return a; }
     static constexpr int OFF_T(int j) { return OFF_SRC(j) + 8 * SS(j); }
     static constexpr int TOTAL = OFF_SRC(NL);
+    // waves have roles: level j owns WV(j) waves (one lane per row-filter item / per column)
+    static constexpr int WV(int j) { return (NG(j) + 7) / 8; }
+    static constexpr int WBASE(int j) { int a = 0; for (int m = 0; m < j; ++m) a += WV(m); return a; }
+    static constexpr int NT = 64 * WBASE(NL);
 };
 
 template <class G, int J>
@@ -471,9 +475,10 @@ __device__ __forceinline__ void march_rowfilter(float *lds, int kid, int tid)
     for (int i = 0; i < KS; ++i) k[i] = c_skern[kid][i];
     const float *srcb = lds + G::OFF_SRC(J);
     float *win = lds + G::OFF_T(J) + 2 * R * TSJ;              // the 8 new rows go behind the 2R rows carried over
-    for (int it = tid; it < ((NGJ + 7) / 8) * 64; it += MARCH_NT) {
+    {
+        const int it = tid;                                      // tid = lane index inside the level's waves
         const int r = (it >> 2) & 7, g = 8 * (it >> 6) + (((it >> 3) & 4) | (it & 3));
-        if (g >= NGJ) continue;
+        if (g >= NGJ) return;
         f32x2 P[4 + 2 * R];
         lds_pairs<false>(P, lds_addr(srcb + r * SSJ + 8 * g), std::make_integer_sequence<int, 4 + 2 * R>());
         float *o = win + r * TSJ + 8 * g;
@@ -529,6 +534,9 @@ __device__ __forceinline__ void march_colfilter(float *lds, int kid, int tid, in
         }
     }
     const int y0 = -G::P + 8 * s - G::L(J);                       // first of the 8 rows produced in this step
+#ifdef MARCH_DIAG_NOSTORE
+    if (acc[0].x == 12345.678f)
+#endif
     if (tid >= HJ && tid < HJ + MARCH_SW && y0 + 7 >= 0 && y0 < h) {
         const unsigned voff = (unsigned)c * 4u;
 #pragma unroll
@@ -548,22 +556,27 @@ __device__ __forceinline__ void march_colfilter(float *lds, int kid, int tid, in
 }
 
 template <int NL, int R0, int R1, int R2>
-__global__ __launch_bounds__(MARCH_NT) void sift_march_kernel(const float *__restrict__ src, long long sstride, float *__restrict__ dst, long long dstride,
-                                                          long long pn, int w, int h, int kid0, float *__restrict__ dec, int dec_level, int w2, int h2)
+__global__ __launch_bounds__(64 * (MarchGeo<NL, R0, R1, R2>::WBASE(NL))) void sift_march_kernel(
+    const float *__restrict__ src, long long sstride, float *__restrict__ dst, long long dstride,
+    long long pn, int w, int h, int kid0, float *__restrict__ dec, int dec_level, int w2, int h2)
 {
+    // All levels work in the same phase on different steps: in iteration t level j is at step t - j (its source rows were
+    // written one iteration earlier), so an iteration has two phases and two barriers whatever NL is -- every level's row
+    // filter, then every level's column filter -- and every wave has work in both.
     typedef MarchGeo<NL, R0, R1, R2> G;
+    constexpr int NT = G::NT;
     __shared__ __attribute__((aligned(16))) float lds[G::TOTAL];
     const int tid = threadIdx.x, x0 = blockIdx.x * MARCH_SW;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // the wave's role is a scalar
     const float *s = src + (long long)blockIdx.y * sstride;
     float *d = dst + (long long)blockIdx.y * dstride;
     float *decp = dec ? dec + (long long)blockIdx.y * dstride : nullptr;
     // this lane's share of the 8 x SRCW(0) source values of a step: fixed (row, column) slots, only the row base moves
-    constexpr int SW0 = G::SRCW(0), NLD = (8 * SW0 + MARCH_NT - 1) / MARCH_NT;
-    static_assert(G::W(0) <= MARCH_NT, "one lane per column");
+    constexpr int SW0 = G::SRCW(0), NLD = (8 * SW0 + NT - 1) / NT;
     int lrow[NLD], lcol[NLD], loff[NLD];
 #pragma unroll
     for (int q = 0; q < NLD; ++q) {
-        const int idx = min(tid + MARCH_NT * q, 8 * SW0 - 1);
+        const int idx = min(tid + NT * q, 8 * SW0 - 1);
         const int r = idx / SW0, cc = idx - r * SW0;
         int c = x0 - G::P + cc;
         c = c < 0 ? -c : c; c = c >= w ? 2 * w - 2 - c : c; c = min(max(c, 0), w - 1);
@@ -580,27 +593,20 @@ __global__ __launch_bounds__(MARCH_NT) void sift_march_kernel(const float *__res
     };
     const int nsteps = (h + 2 * G::P + 7) / 8;
     fetch(0);
-    for (int st = 0; st < nsteps; ++st) {
+    for (int t = 0; t < nsteps + NL - 1; ++t) {
+        if (t < nsteps) {
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) lds[G::OFF_SRC(0) + loff[q]] = stage[q];      // (the clamped duplicates of the last slot rewrite the same value)
-        __syncthreads();
-        if (st + 1 < nsteps) fetch(st + 1);                      // next step's rows fly during this step's arithmetic
-        march_rowfilter<G, 0>(lds, kid0, tid);
-        __syncthreads();
-        march_colfilter<G, 0, NL>(lds, kid0, tid, st, x0, w, h, d, dec_level == 0 ? decp : nullptr, w2, h2);
-        if constexpr (NL > 1) {
-            __syncthreads();
-            march_rowfilter<G, (NL > 1 ? 1 : 0)>(lds, kid0 + 1, tid);
-            __syncthreads();
-            march_colfilter<G, (NL > 1 ? 1 : 0), NL>(lds, kid0 + 1, tid, st, x0, w, h, d + pn, dec_level == 1 ? decp : nullptr, w2, h2);
+            for (int q = 0; q < NLD; ++q) lds[G::OFF_SRC(0) + loff[q]] = stage[q];      // (the clamped duplicates of the last slot rewrite the same value)
         }
-        if constexpr (NL > 2) {
-            __syncthreads();
-            march_rowfilter<G, (NL > 2 ? 2 : 0)>(lds, kid0 + 2, tid);
-            __syncthreads();
-            march_colfilter<G, (NL > 2 ? 2 : 0), NL>(lds, kid0 + 2, tid, st, x0, w, h, d + 2 * pn, dec_level == 2 ? decp : nullptr, w2, h2);
-        }
+        __syncthreads();                                         // source rows of step t in place; every window access of iteration t - 1 done
+        if (t + 1 < nsteps) fetch(t + 1);                        // next step's rows fly during this iteration's arithmetic
+        if (wv < G::WBASE(1)) { if (t < nsteps) march_rowfilter<G, 0>(lds, kid0, tid); }
+        else if (NL > 1 && wv < G::WBASE(NL > 1 ? 2 : 1)) { if (t >= 1 && t - 1 < nsteps) march_rowfilter<G, (NL > 1 ? 1 : 0)>(lds, kid0 + 1, tid - 64 * G::WBASE(1)); }
+        else if (NL > 2) { if (t >= 2 && t - 2 < nsteps) march_rowfilter<G, (NL > 2 ? 2 : 0)>(lds, kid0 + 2, tid - 64 * G::WBASE(NL > 2 ? 2 : 1)); }
         __syncthreads();
+        if (wv < G::WBASE(1)) { if (t < nsteps) march_colfilter<G, 0, NL>(lds, kid0, tid, t, x0, w, h, d, dec_level == 0 ? decp : nullptr, w2, h2); }
+        else if (NL > 1 && wv < G::WBASE(NL > 1 ? 2 : 1)) { if (t >= 1 && t - 1 < nsteps) march_colfilter<G, (NL > 1 ? 1 : 0), NL>(lds, kid0 + 1, tid - 64 * G::WBASE(1), t - 1, x0, w, h, d + pn, dec_level == 1 ? decp : nullptr, w2, h2); }
+        else if (NL > 2) { if (t >= 2 && t - 2 < nsteps) march_colfilter<G, (NL > 2 ? 2 : 0), NL>(lds, kid0 + 2, tid - 64 * G::WBASE(NL > 2 ? 2 : 1), t - 2, x0, w, h, d + 2 * pn, dec_level == 2 ? decp : nullptr, w2, h2); }
     }
 }
 
@@ -1745,9 +1751,9 @@ int rpe_sift_run(rpe_handle *h, const uint8_t *d_a, const uint8_t *d_b, int na, 
                 const bool last = o + 1 >= dv.noct;
                 float *dec = !last ? G + dv.goff[o + 1] : nullptr;
                 const dim3 grid((w + MARCH_SW - 1) / MARCH_SW, g);
-                hipLaunchKernelGGL((sift_march_kernel<3, 5, 6, 8>), grid, dim3(MARCH_NT), 0, h->stream, (const float *)(G + dv.goff[o]), dv.gstride,
+                hipLaunchKernelGGL((sift_march_kernel<3, 5, 6, 8>), grid, dim3(MarchGeo<3, 5, 6, 8>::NT), 0, h->stream, (const float *)(G + dv.goff[o]), dv.gstride,
                                    G + dv.goff[o] + pn, dv.gstride, pn, w, hh, 1, dec, 2, last ? 0 : dv.w[o + 1], last ? 0 : dv.h[o + 1]);
-                hipLaunchKernelGGL((sift_march_kernel<2, 10, 13, 0>), grid, dim3(MARCH_NT), 0, h->stream, (const float *)(G + dv.goff[o] + 3 * pn), dv.gstride,
+                hipLaunchKernelGGL((sift_march_kernel<2, 10, 13, 0>), grid, dim3(MarchGeo<2, 10, 13, 0>::NT), 0, h->stream, (const float *)(G + dv.goff[o] + 3 * pn), dv.gstride,
                                    G + dv.goff[o] + 4 * pn, dv.gstride, pn, w, hh, 4, (float *)nullptr, -1, 0, 0);
                 have_l0 = !last;
                 continue;
