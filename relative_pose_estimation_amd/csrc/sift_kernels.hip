@@ -426,6 +426,10 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
 #ifndef MARCH_SW
 #define MARCH_SW 128
 #endif
+// Workgroup barrier that waits for LDS traffic only: __syncthreads() also drains vmcnt, i.e. every barrier would wait for the
+// level stores of the phase before it (write acknowledgement: microseconds under load) and for the prefetched source rows.
+// The stores have no reader in this kernel and the compiler waits for the prefetch where its registers are used.
+#define MARCH_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define MARCH_NT (MARCH_SW >= 128 ? 256 : 128)     // threads per workgroup: one lane per column of the widest level
 // (lds[addr + 4 TS i], lds[addr + 4 TS (i + 4)]) for every i of the sequence: each half is its own ds_read_b32 at a static
 // offset, so it lands in its half of the register pair (left to the compiler the two uses of a value share one load and
@@ -538,7 +542,6 @@ __device__ __forceinline__ void march_colfilter(float *lds, int kid, int tid, in
     if (acc[0].x == 12345.678f)
 #endif
     if (tid >= HJ && tid < HJ + MARCH_SW && y0 + 7 >= 0 && y0 < h) {
-        const unsigned voff = (unsigned)c * 4u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -546,8 +549,7 @@ __device__ __forceinline__ void march_colfilter(float *lds, int kid, int tid, in
                 const int y = y0 + j + 4 * hh;
                 const float v = hh ? acc[j].y : acc[j].x;
                 if (y >= 0 && y < h) {
-                    // scalar row base + 32-bit lane offset: no 64-bit address arithmetic per store
-                    asm volatile("global_store_dword %0, %1, %2" :: "v"(voff), "v"(v), "s"(plane + (size_t)y * w) : "memory");
+                    (plane + (size_t)y * w)[c] = v;              // a plain store: the compiler's vmcnt bookkeeping must see it (MARCH_BARRIER)
                     if (decp && !(y & 1) && !(c & 1) && (y >> 1) < h2 && (c >> 1) < w2) decp[(size_t)(y >> 1) * w2 + (c >> 1)] = v;
                 }
             }
@@ -598,12 +600,12 @@ __global__ __launch_bounds__(64 * (MarchGeo<NL, R0, R1, R2>::WBASE(NL))) void si
 #pragma unroll
             for (int q = 0; q < NLD; ++q) lds[G::OFF_SRC(0) + loff[q]] = stage[q];      // (the clamped duplicates of the last slot rewrite the same value)
         }
-        __syncthreads();                                         // source rows of step t in place; every window access of iteration t - 1 done
+        MARCH_BARRIER();                                         // source rows of step t in place; every window access of iteration t - 1 done
         if (t + 1 < nsteps) fetch(t + 1);                        // next step's rows fly during this iteration's arithmetic
         if (wv < G::WBASE(1)) { if (t < nsteps) march_rowfilter<G, 0>(lds, kid0, tid); }
         else if (NL > 1 && wv < G::WBASE(NL > 1 ? 2 : 1)) { if (t >= 1 && t - 1 < nsteps) march_rowfilter<G, (NL > 1 ? 1 : 0)>(lds, kid0 + 1, tid - 64 * G::WBASE(1)); }
         else if (NL > 2) { if (t >= 2 && t - 2 < nsteps) march_rowfilter<G, (NL > 2 ? 2 : 0)>(lds, kid0 + 2, tid - 64 * G::WBASE(NL > 2 ? 2 : 1)); }
-        __syncthreads();
+        MARCH_BARRIER();
         if (wv < G::WBASE(1)) { if (t < nsteps) march_colfilter<G, 0, NL>(lds, kid0, tid, t, x0, w, h, d, dec_level == 0 ? decp : nullptr, w2, h2); }
         else if (NL > 1 && wv < G::WBASE(NL > 1 ? 2 : 1)) { if (t >= 1 && t - 1 < nsteps) march_colfilter<G, (NL > 1 ? 1 : 0), NL>(lds, kid0 + 1, tid - 64 * G::WBASE(1), t - 1, x0, w, h, d + pn, dec_level == 1 ? decp : nullptr, w2, h2); }
         else if (NL > 2) { if (t >= 2 && t - 2 < nsteps) march_colfilter<G, (NL > 2 ? 2 : 0), NL>(lds, kid0 + 2, tid - 64 * G::WBASE(NL > 2 ? 2 : 1), t - 2, x0, w, h, d + 2 * pn, dec_level == 2 ? decp : nullptr, w2, h2); }
