@@ -606,7 +606,7 @@ def main():
     extras = []
     if want_extra:
         a3 = argparse.Namespace(**vars(args))
-        a3.config, a3.steps, a3.warmup, a3.unique, a3.cpu_sample, a3.data_cache = 3, 2, 1, 16, 16, ""
+        a3.config, a3.steps, a3.warmup, a3.unique, a3.cpu_sample, a3.data_cache = 3, 3, 1, 128, 16, ""      # 128 distinct rendered pairs (about a minute of the run on 16 cores)
         m3, s3 = resolve(a3)
         d3 = generate(a3, m3, 0, 1, workers)
         extras.append(("config3_128pairs", a3, m3, s3, d3))
