@@ -426,10 +426,6 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float *__res
 #ifndef MARCH_SW
 #define MARCH_SW 128
 #endif
-// Workgroup barrier that waits for LDS traffic only: __syncthreads() also drains vmcnt, i.e. every barrier would wait for the
-// level stores of the phase before it (write acknowledgement: microseconds under load) and for the prefetched source rows.
-// The stores have no reader in this kernel and the compiler waits for the prefetch where its registers are used.
-#define MARCH_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define MARCH_NT (MARCH_SW >= 128 ? 256 : 128)     // threads per workgroup: one lane per column of the widest level
 // (lds[addr + 4 TS i], lds[addr + 4 TS (i + 4)]) for every i of the sequence: each half is its own ds_read_b32 at a static
 // offset, so it lands in its half of the register pair (left to the compiler the two uses of a value share one load and
@@ -549,7 +545,7 @@ __device__ __forceinline__ void march_colfilter(float *lds, int kid, int tid, in
                 const int y = y0 + j + 4 * hh;
                 const float v = hh ? acc[j].y : acc[j].x;
                 if (y >= 0 && y < h) {
-                    (plane + (size_t)y * w)[c] = v;              // a plain store: the compiler's vmcnt bookkeeping must see it (MARCH_BARRIER)
+                    (plane + (size_t)y * w)[c] = v;
                     if (decp && !(y & 1) && !(c & 1) && (y >> 1) < h2 && (c >> 1) < w2) decp[(size_t)(y >> 1) * w2 + (c >> 1)] = v;
                 }
             }
@@ -584,8 +580,12 @@ __global__ __launch_bounds__(64 * (MarchGeo<NL, R0, R1, R2>::WBASE(NL))) void si
         c = c < 0 ? -c : c; c = c >= w ? 2 * w - 2 - c : c; c = min(max(c, 0), w - 1);
         lrow[q] = r; lcol[q] = c; loff[q] = r * G::SS(0) + cc;
     }
-    float stage[NLD];
-    auto fetch = [&](int step) {
+    // Source rows are requested two steps ahead into two register sets.  A set is written to LDS right after the row phase
+    // (whose readers of the previous rows are past the barrier), i.e. BEFORE this iteration's level stores are issued: vmcnt
+    // counts in order, so waiting for a set drains every older request -- with the wait placed after the stores (one set, one
+    // step ahead) every iteration sat out the write acknowledgement of the stores it had just issued.
+    float sA[NLD], sB[NLD];
+    auto fetch = [&](float (&stage)[NLD], int step) {
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
             int y = -G::P + 8 * step + lrow[q];
@@ -593,22 +593,34 @@ __global__ __launch_bounds__(64 * (MarchGeo<NL, R0, R1, R2>::WBASE(NL))) void si
             stage[q] = s[(size_t)y * w + lcol[q]];
         }
     };
-    const int nsteps = (h + 2 * G::P + 7) / 8;
-    fetch(0);
-    for (int t = 0; t < nsteps + NL - 1; ++t) {
-        if (t < nsteps) {
+    auto put = [&](const float (&stage)[NLD]) {
 #pragma unroll
-            for (int q = 0; q < NLD; ++q) lds[G::OFF_SRC(0) + loff[q]] = stage[q];      // (the clamped duplicates of the last slot rewrite the same value)
-        }
-        MARCH_BARRIER();                                         // source rows of step t in place; every window access of iteration t - 1 done
-        if (t + 1 < nsteps) fetch(t + 1);                        // next step's rows fly during this iteration's arithmetic
+        for (int q = 0; q < NLD; ++q) lds[G::OFF_SRC(0) + loff[q]] = stage[q];      // (the clamped duplicates of the last slot rewrite the same value)
+    };
+    const int nsteps = (h + 2 * G::P + 7) / 8;
+    // iteration t: level j is at step t - j (its source rows were written one iteration earlier)
+    auto iter = [&](int t, float (&cur)[NLD]) {
         if (wv < G::WBASE(1)) { if (t < nsteps) march_rowfilter<G, 0>(lds, kid0, tid); }
         else if (NL > 1 && wv < G::WBASE(NL > 1 ? 2 : 1)) { if (t >= 1 && t - 1 < nsteps) march_rowfilter<G, (NL > 1 ? 1 : 0)>(lds, kid0 + 1, tid - 64 * G::WBASE(1)); }
         else if (NL > 2) { if (t >= 2 && t - 2 < nsteps) march_rowfilter<G, (NL > 2 ? 2 : 0)>(lds, kid0 + 2, tid - 64 * G::WBASE(NL > 2 ? 2 : 1)); }
-        MARCH_BARRIER();
+        __syncthreads();
+        if (t + 1 < nsteps) put(cur);                            // source rows of step t + 1 (requested two iterations ago)
         if (wv < G::WBASE(1)) { if (t < nsteps) march_colfilter<G, 0, NL>(lds, kid0, tid, t, x0, w, h, d, dec_level == 0 ? decp : nullptr, w2, h2); }
         else if (NL > 1 && wv < G::WBASE(NL > 1 ? 2 : 1)) { if (t >= 1 && t - 1 < nsteps) march_colfilter<G, (NL > 1 ? 1 : 0), NL>(lds, kid0 + 1, tid - 64 * G::WBASE(1), t - 1, x0, w, h, d + pn, dec_level == 1 ? decp : nullptr, w2, h2); }
         else if (NL > 2) { if (t >= 2 && t - 2 < nsteps) march_colfilter<G, (NL > 2 ? 2 : 0), NL>(lds, kid0 + 2, tid - 64 * G::WBASE(NL > 2 ? 2 : 1), t - 2, x0, w, h, d + 2 * pn, dec_level == 2 ? decp : nullptr, w2, h2); }
+        // requested AFTER this iteration's stores and unconditionally (rows past the end are clamped): vmcnt counts in order, so the
+        // next wait (for the other set) can name exactly these NLD requests as the ones that may stay in flight
+        fetch(cur, t + 3);
+        __syncthreads();                                         // every window access of this iteration done; step t + 1's rows in place
+    };
+    fetch(sA, 0); fetch(sB, 1);
+    put(sA);
+    __syncthreads();
+    fetch(sA, 2);
+    const int T = nsteps + NL - 1;
+    for (int t = 0; t < T; t += 2) {
+        iter(t, sB);
+        iter(t + 1, sA);                                         // (an iteration past the end finds nothing to do)
     }
 }
 
