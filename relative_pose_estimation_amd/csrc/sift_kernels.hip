@@ -1361,6 +1361,7 @@ __global__ __launch_bounds__(256) void sift_finalize_kernel(const float *__restr
 // One keypoint per 64-lane workgroup: the 15 KB of accumulators per keypoint decide the occupancy (four keypoints per
 // workgroup were 61 KB: 2 workgroups = 8 waves per CU; one per workgroup gives 10).
 #define SIFT_DESC_KPW 1
+#define S_DESC_ROWS 128       // rows of the sample square: 2 radius + 1 <= 77 (radius = round(3 scl sqrt2 2.5), scl <= 1.6 * 2^(3.5/3))
 __global__ __launch_bounds__(64 * SIFT_DESC_KPW) void sift_describe_kernel(const float *__restrict__ gauss, SiftDev dv, const float *__restrict__ fin,
                                                              const int *__restrict__ kp_count, uint8_t *__restrict__ desc)
 {
@@ -1370,7 +1371,7 @@ __global__ __launch_bounds__(64 * SIFT_DESC_KPW) void sift_describe_kernel(const
     __shared__ float s_part[SIFT_DESC_KPW][160][8];
     __shared__ float s_hist[SIFT_DESC_KPW][160];
     __shared__ float s_stage[SIFT_DESC_KPW][64 * 9];
-    __shared__ unsigned s_list[SIFT_DESC_KPW][64 * 9];     // raster indices of the samples inside the rotated grid, not yet consumed (< 64 + 64 DCH)
+    __shared__ int s_ja[SIFT_DESC_KPW][S_DESC_ROWS], s_pre[SIFT_DESC_KPW][S_DESC_ROWS + 1];   // per raster row: first valid column, samples before the row
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int kidx = blockIdx.x * SIFT_DESC_KPW + wv, img = blockIdx.y;
     if (kidx >= kp_count[img]) return;
@@ -1398,56 +1399,76 @@ __global__ __launch_bounds__(64 * SIFT_DESC_KPW) void sift_describe_kernel(const
     float *stg = s_stage[wv];
     for (int i = lane; i < 160 * 8; i += 64) (&part[0][0])[i] = 0.f;
     S_WAVE_SYNC();
-    const int side = 2 * radius + 1, nsamp = side * side;
-    const float inv_side = 1.f / (float)side;
-    // Two phases per chunk of 64 * DCH raster positions of the bounding square.  Phase 1 tests every position against the rotated
-    // 4 x 4 grid and the image border (calcSIFTDescriptor's first loop) and appends the raster indices of those that pass to an
-    // LDS list, in raster order (ballot + prefix count): only half of the square lies inside the rotated grid.  Phase 2 takes
-    // the list 64 entries at a time -- dense batches: every lane has a sample -- and does the expensive part (gradient loads,
-    // exp, atan2, trilinear weights, accumulation).  Sample number k counts the samples that passed, as cv2's arrays do.
-    constexpr int DCH = 8;
+    const int side = 2 * radius + 1;
+    // calcSIFTDescriptor's first loop keeps the positions (i, j) of the bounding square that lie inside the rotated 4 x 4 grid
+    // and off the image border, in raster order -- about half of the square.  Each of its conditions is a float expression that
+    // is monotone in j (products and sums round monotonically), so the positions kept in a row are an interval [ja, jb]:
+    // one lane per row finds it (real-valued bounds, widened by one, then moved inward / outward with the exact predicate),
+    // a wave scan numbers the samples, and the expensive part below runs on dense batches of 64 samples whose (i, j) come from
+    // the row table.  Sample number k counts the samples that pass, as cv2's arrays do.
     constexpr int DU = 4;                                   // dense batches whose gradient loads fly together
-    unsigned *lst = s_list[wv];
-    int pending = 0;                                        // list entries not yet consumed (wave-uniform)
-    auto locate = [&](int k, float &crot, float &rrot, float &rbn, float &cbn, int &r, int &c) {
-        // k / side without the integer divider: float estimate, one correction step (k < 2^24)
-        int qi = (int)((float)k * inv_side);
-        int rem = k - qi * side;
-        if (rem < 0) { --qi; rem += side; } else if (rem >= side) { ++qi; rem -= side; }
-        const int i = qi - radius, j = rem - radius;
-        crot = j * cos_t - i * sin_t; rrot = j * sin_t + i * cos_t;
-        rbn = rrot + d / 2 - 0.5f; cbn = crot + d / 2 - 0.5f;
-        r = py + i; c = px + j;
+    int *rja = s_ja[wv], *rpre = s_pre[wv];
+    auto okpos = [&](int i, int j) -> bool {
+        const float crot = j * cos_t - i * sin_t, rrot = j * sin_t + i * cos_t;
+        const float rbn = rrot + d / 2 - 0.5f, cbn = crot + d / 2 - 0.5f;
+        const int r = py + i, c = px + j;
+        return rbn > -1 && rbn < d && cbn > -1 && cbn < d && r > 0 && r < h - 1 && c > 0 && c < w - 1;
     };
-    for (int k0 = 0; k0 < nsamp; k0 += 64 * DCH) {
-#pragma unroll
-        for (int u = 0; u < DCH; ++u) {
-            if (k0 + 64 * u >= nsamp) break;                                  // wave-uniform
-            const int k = k0 + 64 * u + lane;
-            float crot, rrot, rbn, cbn; int r, c;
-            locate(k, crot, rrot, rbn, cbn, r, c);
-            const bool ok = k < nsamp && rbn > -1 && rbn < d && cbn > -1 && cbn < d && r > 0 && r < h - 1 && c > 0 && c < w - 1;
-            const unsigned long long m = __ballot(ok);
-            if (ok) lst[pending + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned)k;
-            pending += __popcll(m);
+    int ntotal = 0;                                         // wave-uniform
+    if (side > S_DESC_ROWS) return;                         // cannot happen (see S_DESC_ROWS); no descriptor rather than a wrong one
+    for (int r0 = 0; r0 < side; r0 += 64) {
+        const int row = r0 + lane, i = row - radius;
+        int ja = 0, cnt = 0;
+        if (row < side) {
+            const int jmin = max(-radius, 1 - px), jmax = min(radius, w - 2 - px);
+            // |j S + i C| < 2.5 and |j C - i S| < 2.5 solved for j where the coefficient is not tiny (an estimate only)
+            float lo = (float)jmin, hi = (float)jmax;
+            if (fabsf(sin_t) >= 1e-3f) {
+                const float a = (-2.5f - i * cos_t) / sin_t, b = (2.5f - i * cos_t) / sin_t;
+                lo = fmaxf(lo, fminf(a, b)); hi = fminf(hi, fmaxf(a, b));
+            }
+            if (fabsf(cos_t) >= 1e-3f) {
+                const float a = (-2.5f + i * sin_t) / cos_t, b = (2.5f + i * sin_t) / cos_t;
+                lo = fmaxf(lo, fminf(a, b)); hi = fminf(hi, fmaxf(a, b));
+            }
+            int jl = max(jmin, (int)floorf(lo) - 1), jh = min(jmax, (int)ceilf(hi) + 1);
+            while (jl <= jh && !okpos(i, jl)) ++jl;         // inward to the first / last position that passes
+            while (jh >= jl && !okpos(i, jh)) --jh;
+            if (jl <= jh) {                                  // outward: the estimate is a superset unless rounding says otherwise
+                while (jl > jmin && okpos(i, jl - 1)) --jl;
+                while (jh < jmax && okpos(i, jh + 1)) ++jh;
+                ja = jl; cnt = jh - jl + 1;
+            }
         }
-        S_WAVE_SYNC();
-        const bool last_chunk = k0 + 64 * DCH >= nsamp;
-        const int nb = last_chunk ? (pending + 63) >> 6 : pending >> 6;
+        int incl = cnt;                                      // inclusive scan over the 64 rows of this pass
+#pragma unroll
+        for (int of = 1; of < 64; of <<= 1) { const int t = __shfl_up(incl, of); if (lane >= of) incl += t; }
+        if (row < side) { rja[row] = ja; rpre[row] = ntotal + incl - cnt; }
+        ntotal += __shfl(incl, 63);
+    }
+    if (lane == 0) rpre[side] = ntotal;
+    S_WAVE_SYNC();
+    const int nb = (ntotal + 63) >> 6;
+    int rstart = 0;                                         // row of the last sample of the previous batch (wave-uniform)
+    {
         for (int b0 = 0; b0 < nb; b0 += DU) {
         bool vld[DU];
         float crot[DU], rrot[DU], rbn[DU], cbn[DU], g0[DU], g1[DU], g2[DU], g3[DU];
 #pragma unroll
         for (int u = 0; u < DU; ++u) {
             const int e = (b0 + u) * 64 + lane;
-            vld[u] = b0 + u < nb && e < pending;
+            vld[u] = b0 + u < nb && e < ntotal;
             g0[u] = g1[u] = g2[u] = g3[u] = 0.f; crot[u] = rrot[u] = rbn[u] = cbn[u] = 0.f;
+            int row = rstart;
             if (vld[u]) {
-                int r, c;
-                locate((int)lst[e], crot[u], rrot[u], rbn[u], cbn[u], r, c);
-                const float *pc = img_l + (size_t)r * w + c;
+                while (rpre[row + 1] <= e) ++row;           // a batch spans a few rows (empty ones included)
+                const int i = row - radius, j = rja[row] + (e - rpre[row]);
+                crot[u] = j * cos_t - i * sin_t; rrot[u] = j * sin_t + i * cos_t;
+                rbn[u] = rrot[u] + d / 2 - 0.5f; cbn[u] = crot[u] + d / 2 - 0.5f;
+                const float *pc = img_l + (size_t)(py + i) * w + (px + j);
                 g0[u] = pc[1]; g1[u] = pc[-1]; g2[u] = pc[-w]; g3[u] = pc[w];
             }
+            if (b0 + u < nb) rstart = __shfl(row, min(63, ntotal - 1 - (b0 + u) * 64));     // last valid lane of the batch
         }
 #pragma unroll
         for (int u = 0; u < DU; ++u) {
@@ -1508,14 +1529,6 @@ __global__ __launch_bounds__(64 * SIFT_DESC_KPW) void sift_describe_kernel(const
             }
         }
         }
-        }
-        if (!last_chunk) {                                  // the incomplete batch moves to the front of the list
-            const int rem = pending & 63;
-            const unsigned keep = lane < rem ? lst[nb * 64 + lane] : 0u;
-            S_WAVE_SYNC();
-            if (lane < rem) lst[lane] = keep;
-            S_WAVE_SYNC();
-            pending = rem;
         }
     }
     S_WAVE_SYNC();
