@@ -755,18 +755,27 @@ __global__ __launch_bounds__(256) void sift_extrema_mask_kernel(const float *__r
         rowmm(rb + 1, pmx[1], pmn[1], ctr[1]);
         const int x = x0 + cb + lane;
         const bool xin = x >= S_BORDER && x < w - S_BORDER;
+        // mask word / band counter of this wave's first row; the rows below are one word row / one counter further (the scalar
+        // unit is shared by the CU's four SIMDs: per-row 64-bit index arithmetic made this kernel issue as many scalar
+        // instructions as vector ones)
+        const int wpr = dv.wpr[o];
+        unsigned long long *mrow = mk + ((long long)(l - 1) * h + (y0 + rb)) * wpr + ((x0 + cb) >> 6);
+        int *brow = bc + (l - 1) * (h - 2 * S_BORDER) + (y0 + rb - S_BORDER);
+        const bool colin = x0 + cb < w;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int rr = rb + k, y = y0 + rr;
-            rowmm(rr + 2, pmx[2], pmn[2], ctr[2]);
+            const int y = y0 + rb + k;
+            rowmm(rb + k + 2, pmx[2], pmn[2], ctr[2]);
             const float M = fmaxf(fmaxf(pmx[0], pmx[1]), pmx[2]), m = fminf(fminf(pmn[0], pmn[1]), pmn[2]);
             const float val = ctr[1];
-            const bool yin = y >= S_BORDER && y < h - S_BORDER;       // wave-uniform
-            const bool hit = yin && xin && fabsf(val) > 1.f && ((val > 0.f && val >= M) || (val < 0.f && val <= m));
-            const unsigned long long bal = __ballot(hit);
-            if (lane == 0 && yin && x0 + cb < w) {
-                mk[((long long)(l - 1) * h + y) * dv.wpr[o] + ((x0 + cb) >> 6)] = bal;
-                if (bal) atomicAdd(&bc[(l - 1) * (h - 2 * S_BORDER) + (y - S_BORDER)], __popcll(bal));
+            if (y >= S_BORDER && y < h - S_BORDER && colin) {            // wave-uniform
+                // "no neighbour is greater / smaller": M and m include val itself, so val >= M <=> val == M, val <= m <=> val == m
+                const bool hit = xin && fabsf(val) > 1.f && val == (val > 0.f ? M : m);
+                const unsigned long long bal = __ballot(hit);
+                if (lane == 0) {
+                    mrow[(long long)k * wpr] = bal;
+                    if (bal) atomicAdd(brow + k, __popcll(bal));
+                }
             }
             pmx[0] = pmx[1]; pmx[1] = pmx[2]; pmn[0] = pmn[1]; pmn[1] = pmn[2]; ctr[0] = ctr[1]; ctr[1] = ctr[2];
         }
