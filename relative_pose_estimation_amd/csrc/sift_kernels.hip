@@ -14,11 +14,16 @@
 //   extrema   : tiled 26-neighbour test (rolling LDS layers with halo columns, 3x3x3 max/min from LDS reads) -> 1-bit hit
 //               mask + one counter per (octave, layer, row) band; parallel band scan; wave-per-row emit = raster-ordered seeds
 //   adjust    : one lane per seed: adjustLocalExtrema (contrast / edge tests); survivors appended by integer atomics
-//   orient    : one wave per survivor: 36-bin orientation histogram in 8 interleaved partials per bin (per-slot order
+//   select    : under a cap only the nfeatures * 5/4 + 256 strongest survivors (radix select on |contrast|) get an orientation;
+//               exact because retainBest's threshold lies inside them (a second round covers the case that it does not)
+//   orient    : one wave per selected survivor: 36-bin orientation histogram in 8 interleaved partials per bin (per-slot order
 //               kept in registers by DPP row shifts), Gaussian weights from a per-keypoint table, peaks -> raw keypoints
 //   sort      : response prefilter, bitonic sort of the raw keypoints by KeyPoint_LessThan (one workgroup / image)
 //   finalize  : duplicate removal, retainBest(nfeatures) by radix select, ordered compaction
-//   describe  : one wave per keypoint, 4x4x8 trilinear histogram in 8 interleaved partials, lane = (slot, corner)
+//   describe  : one wave per keypoint: the sample positions kept in a row of the square are an interval (one lane per row finds
+//               it), dense batches of 64 samples, 4x4x8 trilinear histogram in 8 interleaved partials, lane = (slot, corner)
+//   march     : (RPE_SIFT_MARCH=1) levels 1-3 / 4-5 of the large octaves in one pass over the source level each, rings of
+//               row-filtered rows in LDS; bit-identical to the tile kernels
 // Kernels whose lanes append through a returning atomic on a per-image counter (adjust, orient) put the image index on
 // the fastest grid axis, so that workgroups in flight together hit different counters.
 #include "rpe_internal.h"
